@@ -1,0 +1,207 @@
+"""ctypes binding of libdreamer_amd.so (include/dreamer_amd.h).
+
+The library is the product path on a GPU: there is no other implementation behind these
+wrappers, and every wrapper raises if the shared object is missing or a call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdreamer_amd.so")
+_lib = None
+
+DRM_MAX_MLP_LAYERS = 4
+_f32p = C.POINTER(C.c_float)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class drm_ring(C.Structure):
+    _fields_ = [("observations", C.c_void_p), ("actions", C.c_void_p), ("rewards", C.c_void_p),
+                ("continues", C.c_void_p), ("capacity", C.c_int64), ("frame_bytes", C.c_int64)]
+
+
+class drm_linear_args(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+                ("W", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("table", C.c_void_p),
+                ("ldt", C.c_int64), ("zidx", C.c_void_p), ("ldz", C.c_int64), ("latents", C.c_int32),
+                ("classes", C.c_int32), ("Y", C.c_void_p), ("ldy", C.c_int64), ("M", C.c_int32),
+                ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class drm_mlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32),
+                ("w", C.c_void_p * DRM_MAX_MLP_LAYERS), ("b", C.c_void_p * DRM_MAX_MLP_LAYERS),
+                ("ln_g", C.c_void_p * DRM_MAX_MLP_LAYERS), ("ln_b", C.c_void_p * DRM_MAX_MLP_LAYERS),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+
+
+class drm_dims(C.Structure):
+    _fields_ = [("D", C.c_int32), ("L", C.c_int32), ("K", C.c_int32), ("M", C.c_int32), ("A", C.c_int32),
+                ("E", C.c_int32), ("NB", C.c_int32), ("unimix_eps", C.c_float)]
+
+
+class drm_imagine_weights(C.Structure):
+    _fields_ = [("dims", drm_dims), ("a_emb", C.c_void_p), ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
+                ("gru_w_ih", C.c_void_p), ("gru_w_hh", C.c_void_p), ("gru_b_ih", C.c_void_p),
+                ("gru_b_hh", C.c_void_p), ("dyn", drm_mlp), ("rew", drm_mlp), ("cont", drm_mlp),
+                ("actor", drm_mlp), ("critic", drm_mlp), ("buckets", C.c_void_p), ("pack", C.c_void_p),
+                ("pack_bytes", C.c_size_t)]
+
+
+class drm_imagine_io(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("h0", C.c_void_p), ("zidx0", C.c_void_p),
+                ("expo_a", C.c_void_p), ("expo_z", C.c_void_p), ("forced_actions", C.c_void_p),
+                ("forced_zidx", C.c_void_p), ("h_out", C.c_void_p), ("zidx_out", C.c_void_p),
+                ("zidx_sampled_out", C.c_void_p), ("z_out", C.c_void_p), ("actions_out", C.c_void_p),
+                ("actions_sampled_out", C.c_void_p), ("actor_logp_out", C.c_void_p),
+                ("prior_logits_out", C.c_void_p), ("rewards_out", C.c_void_p), ("conts_out", C.c_void_p),
+                ("values_out", C.c_void_p), ("v_last_out", C.c_void_p), ("lam_returns_out", C.c_void_p),
+                ("gamma", C.c_double), ("lam", C.c_double), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+# name -> (restype, argtypes); must list every symbol include/dreamer_amd.h declares
+SIGNATURES = {
+    "drm_version": (C.c_int, []),
+    "drm_last_error": (C.c_char_p, []),
+    "drm_arch_ok": (C.c_int, []),
+    "drm_lambda_return": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
+    "drm_seq_gather": (C.c_int, [C.POINTER(drm_ring), C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
+    "drm_sample_categorical_st": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "drm_onehot_to_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "drm_fused_linear_f32": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
+    "drm_pack_imagine_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
+    "drm_pack_imagine": (C.c_int, [C.POINTER(drm_imagine_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
+    "drm_imagine_block_f32": (C.c_int, [C.POINTER(drm_imagine_weights), C.POINTER(drm_imagine_io), C.c_void_p]),
+}
+
+
+def lib():
+    """The loaded shared library; raises NativeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              f"g.build()'` (or `make -C dreamer_amd/csrc`). There is no fallback path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise NativeError(f"{what} failed with code {rc}: {lib().drm_last_error().decode()}")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NativeError("this operation runs only on a HIP device tensor")
+
+
+def _dense(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if t.dtype != dtype or not t.is_contiguous():
+        raise NativeError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+# --------------------------------------------------------------------------- thin wrappers
+def lambda_return(R, C_, V, V_last, gamma: float, lam: float) -> torch.Tensor:
+    require_cuda(R, C_, V, V_last)
+    B, H = R.shape
+    for n, t in (("R", R), ("C", C_), ("V", V), ("V_last", V_last)):
+        _dense(t, torch.float32, n)
+    out = torch.empty_like(R)
+    check(lib().drm_lambda_return(R.data_ptr(), C_.data_ptr(), V.data_ptr(), V_last.data_ptr(), out.data_ptr(),
+                                  B, H, float(gamma), float(lam), stream_ptr(R.device)), "drm_lambda_return")
+    return out
+
+
+def seq_gather(obs, actions, rewards, continues, starts, T: int, want_f32: bool = False):
+    require_cuda(obs, actions, rewards, continues, starts)
+    cap = obs.shape[0]
+    frame = obs[0].numel()
+    _dense(obs, torch.uint8, "observations"); _dense(actions, torch.int64, "actions")
+    _dense(rewards, torch.float32, "rewards"); _dense(continues, torch.bool, "continues")
+    _dense(starts, torch.int64, "starts")
+    B = starts.numel()
+    dev = obs.device
+    o = torch.empty((B, T, *obs.shape[1:]), dtype=torch.uint8, device=dev)
+    a = torch.empty((B, T), dtype=torch.int64, device=dev)
+    r = torch.empty((B, T), dtype=torch.float32, device=dev)
+    c = torch.empty((B, T), dtype=torch.bool, device=dev)
+    f = torch.empty((B, T, *obs.shape[1:]), dtype=torch.float32, device=dev) if want_f32 else None
+    ring = drm_ring(obs.data_ptr(), actions.data_ptr(), rewards.data_ptr(), continues.data_ptr(), cap, frame)
+    check(lib().drm_seq_gather(C.byref(ring), starts.data_ptr(), B, T, o.data_ptr(), a.data_ptr(), r.data_ptr(),
+                               c.data_ptr(), ptr(f), stream_ptr(dev)), "drm_seq_gather")
+    return o, a, r, c, f
+
+
+def sample_categorical_st(logits, expo, unimix_eps: Optional[float], want_z=True, want_idx=True, want_y=False):
+    require_cuda(logits, expo)
+    _dense(logits, torch.float32, "logits"); _dense(expo, torch.float32, "expo")
+    K = logits.shape[-1]
+    rows = logits.numel() // K
+    dev = logits.device
+    z = torch.empty_like(logits) if want_z else None
+    idx = torch.empty(logits.shape[:-1], dtype=torch.uint8, device=dev) if want_idx else None
+    y = torch.empty_like(logits) if want_y else None
+    eps = -1.0 if unimix_eps is None else float(unimix_eps)
+    check(lib().drm_sample_categorical_st(logits.data_ptr(), expo.data_ptr(), rows, K, eps, ptr(z), ptr(idx), ptr(y),
+                                          stream_ptr(dev)), "drm_sample_categorical_st")
+    return z, idx, y
+
+
+def onehot_to_index(z: torch.Tensor) -> torch.Tensor:
+    require_cuda(z)
+    _dense(z, torch.float32, "z")
+    K = z.shape[-1]
+    idx = torch.empty(z.shape[:-1], dtype=torch.uint8, device=z.device)
+    check(lib().drm_onehot_to_index(z.data_ptr(), z.numel() // K, K, idx.data_ptr(), stream_ptr(z.device)),
+          "drm_onehot_to_index")
+    return idx
+
+
+def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None):
+    """Y = f(x) @ w[:, :K]^T + bias (+ one-hot table rows).  ``w`` may be wider than K (``w_cols`` = K)."""
+    require_cuda(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if w_cols is not None:
+        assert w_cols == K
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    a = drm_linear_args()
+    a.X, a.ldx = x.data_ptr(), x.stride(0)
+    if ln is not None:
+        a.ln_gamma, a.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+    a.W, a.ldw = w.data_ptr(), w.stride(0)
+    a.bias = ptr(bias)
+    if table is not None:
+        a.table, a.ldt = table.data_ptr(), table.stride(0)
+        a.zidx, a.ldz = zidx.data_ptr(), zidx.stride(0)
+        a.latents, a.classes = zidx.shape[1], classes
+    a.Y, a.ldy = y.data_ptr(), y.stride(0)
+    a.M, a.N, a.K = M, N, K
+    check(lib().drm_fused_linear_f32(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_f32")
+    return y

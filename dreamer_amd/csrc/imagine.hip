@@ -1,0 +1,538 @@
+// Imagination block (actor -> action -> prior RSSM step, H times; heads; critic value;
+// lambda-return) as a chain of fused-linear launches.  Every layer boundary is an all-to-all over
+// the feature dimension (LayerNorm and the next matmul need whole rows), so each is a kernel
+// boundary; inside a kernel the output columns are spread over the CUs.
+#include "linear16.hpp"
+
+namespace drm {
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: one-hot gather tables.
+// ------------------------------------------------------------------------------------------------
+// out[c][n] = W[n][col0 + c]   (c < ncols, n < nrows)
+__global__ __launch_bounds__(256) void k_transpose_cols(const float* __restrict__ W, int64_t ldw, int col0, int ncols,
+                                                         int nrows, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, c = c0 + tx;
+        tile[i][tx] = (n < nrows && c < ncols) ? W[(int64_t)n * ldw + col0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, n = n0 + tx;
+        if (c < ncols && n < nrows) out[(int64_t)c * nrows + n] = tile[tx][i];
+    }
+}
+
+// a_tab[a][j] = sum_e lin_w[j][LK + e] * a_emb[a][e]
+__global__ __launch_bounds__(256) void k_action_table(const float* __restrict__ lin_w, int64_t ldw, int col0, int E,
+                                                       const float* __restrict__ a_emb, int A, int D,
+                                                       float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.y;
+    if (j >= D) return;
+    const float* w = lin_w + (int64_t)j * ldw + col0;
+    const float* e = a_emb + (int64_t)a * E;
+    float s = 0.f;
+    for (int i = 0; i < E; ++i) s = fmaf(w[i], e[i], s);
+    out[(int64_t)a * D + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide sum over 256 threads (4 waves)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* s4) {
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// actor head + action draw + GRU input row, one workgroup per trajectory:
+//   act = SiLU(LN(pre));  logits = head(act);  logp = normalise(log_unimix(logits));
+//   a = argmax(softmax(logp) / E);  x = lin_b + sum_l lin_zT[l*K + z_l] + a_tab[a]
+// (lib/actor.py:94-106, Categorical.sample, lib/world_model.py:64-70 with one-hot z)
+// ------------------------------------------------------------------------------------------------
+struct ActorHeadArgs {
+    const float* pre; int64_t ldp;
+    const float* ln_g; const float* ln_b;
+    const float* head_w; const float* head_b;
+    int M, A;
+    const float* expo; int64_t lde;          // (B, A)
+    const int64_t* forced; int64_t ldf;      // (B) strided or nullptr
+    float log1m_eps, log_eps_over_a;
+    const uint8_t* zidx; int64_t ldz; int latents, classes;
+    const float* lin_zT; const float* lin_b; const float* a_tab; int D;
+    float* x; int64_t ldxo;
+    int64_t* a_used; int64_t ldau;
+    int64_t* a_sampled; int64_t ldas;        // nullable
+    float* logp_out; int64_t ldlp;           // nullable
+};
+
+__global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float s_act[];   // M floats
+    __shared__ float s4[4];
+    __shared__ float s_logit[64];
+    __shared__ int s_a;
+    __shared__ uint8_t s_z[256];
+    const int b = blockIdx.x;
+    const float* pre = P.pre + (int64_t)b * P.ldp;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P.M; i += 256) { const float v = pre[i]; s_act[i] = v; s += v; }
+    const float mean = block_sum_256(s, s4) / (float)P.M;
+    float qv = 0.f;
+    for (int i = threadIdx.x; i < P.M; i += 256) { const float d = s_act[i] - mean; qv += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum_256(qv, s4) / (float)P.M + LN_EPS);
+    for (int i = threadIdx.x; i < P.M; i += 256) s_act[i] = silu_f((s_act[i] - mean) * rstd * P.ln_g[i] + P.ln_b[i]);
+    for (int l = threadIdx.x; l < P.latents; l += 256) s_z[l] = P.zidx[(int64_t)b * P.ldz + l];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int a = wave; a < P.A; a += 4) {
+        const float* w = P.head_w + (int64_t)a * P.M;
+        float d = 0.f;
+        for (int i = lane; i < P.M; i += 64) d = fmaf(s_act[i], w[i], d);
+        d = group_sum<64>(d);
+        if (lane == 0) s_logit[a] = d + P.head_b[a];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool on = lane < P.A;
+        const float NEG = -3.0e38f;
+        const float lg = on ? s_logit[lane] : NEG;
+        const float mx = group_max<64>(lg);
+        const float lse = logf(group_sum<64>(on ? expf(lg - mx) : 0.f));
+        const float mixed = on ? logaddexp_f((lg - mx - lse) + P.log1m_eps, P.log_eps_over_a) : NEG;
+        // Categorical(logits=mixed) normalises once more
+        const float mx2 = group_max<64>(mixed);
+        const float lse2 = mx2 + logf(group_sum<64>(on ? expf(mixed - mx2) : 0.f));
+        const float logp = mixed - lse2;
+        // probs = softmax(logp); multinomial draws argmax(probs / E)
+        const float mx3 = group_max<64>(on ? logp : NEG);
+        const float ex = on ? expf(logp - mx3) : 0.f;
+        const float prob = ex / group_sum<64>(ex);
+        float score = on ? prob / P.expo[(int64_t)b * P.lde + lane] : -1.f;
+        int ai = lane;
+        group_argmax<64>(score, ai);
+        if (on && P.logp_out) P.logp_out[(int64_t)b * P.ldlp + lane] = logp;
+        if (lane == 0) {
+            int used = ai;
+            if (P.forced) used = (int)P.forced[(int64_t)b * P.ldf];
+            s_a = used;
+            P.a_used[(int64_t)b * P.ldau] = used;
+            if (P.a_sampled) P.a_sampled[(int64_t)b * P.ldas] = ai;
+        }
+    }
+    __syncthreads();
+    const int a = s_a;
+    for (int j = threadIdx.x; j < P.D; j += 256) {
+        float acc = P.lin_b[j];
+        for (int l = 0; l < P.latents; ++l) acc += P.lin_zT[(int64_t)(l * P.classes + s_z[l]) * P.D + j];
+        acc += P.a_tab[(int64_t)a * P.D + j];
+        P.x[(int64_t)b * P.ldxo + j] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar heads: out = post(head_w . SiLU(LN(pre row)) + head_b); one wave per (row, head)
+// (lib/world_model.py:215-216, :259-260 and lib/trainer.py:193-194)
+// ------------------------------------------------------------------------------------------------
+struct ScalarHead {
+    const float* pre; int64_t ldp;
+    const float* ln_g; const float* ln_b;
+    const float* head_w; const float* head_b;
+    float* out;        // post-processed value per row
+    float* raw_out;    // raw head output per row or nullptr
+    int post;          // 0 none, 1 symexp, 2 sigmoid
+};
+struct ScalarHeadsArgs { ScalarHead h[2]; int nh; int rows; int M; };
+
+__global__ __launch_bounds__(256) void k_scalar_heads(const ScalarHeadsArgs P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= P.rows) return;
+    for (int hi = 0; hi < P.nh; ++hi) {
+        const ScalarHead& Hd = P.h[hi];
+        const float* pre = Hd.pre + (int64_t)row * Hd.ldp;
+        float s = 0.f;
+        for (int i = lane * 4; i < P.M; i += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(pre + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        const float mean = group_sum<64>(s) / (float)P.M;
+        float qv = 0.f;
+        for (int i = lane * 4; i < P.M; i += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(pre + i);
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            qv += (a * a + b * b) + (c * c + d * d);
+        }
+        const float rstd = 1.0f / sqrtf(group_sum<64>(qv) / (float)P.M + LN_EPS);
+        float dot = 0.f;
+        for (int i = lane * 4; i < P.M; i += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(pre + i);
+            const float4 g = *reinterpret_cast<const float4*>(Hd.ln_g + i);
+            const float4 e = *reinterpret_cast<const float4*>(Hd.ln_b + i);
+            const float4 w = *reinterpret_cast<const float4*>(Hd.head_w + i);
+            dot = fmaf(silu_f((v.x - mean) * rstd * g.x + e.x), w.x, dot);
+            dot = fmaf(silu_f((v.y - mean) * rstd * g.y + e.y), w.y, dot);
+            dot = fmaf(silu_f((v.z - mean) * rstd * g.z + e.z), w.z, dot);
+            dot = fmaf(silu_f((v.w - mean) * rstd * g.w + e.w), w.w, dot);
+        }
+        dot = group_sum<64>(dot) + Hd.head_b[0];
+        if (lane == 0) {
+            if (Hd.raw_out) Hd.raw_out[row] = dot;
+            Hd.out[row] = Hd.post == 1 ? symexp_f(dot) : (Hd.post == 2 ? sigmoid_f(dot) : dot);
+        }
+    }
+}
+
+// critic value: symexp(sum softmax(logits) * buckets), one wave per row (lib/critic.py:94-101);
+// also copies the value of each trajectory's last step to v_last (lib/trainer.py:212-215).
+__global__ __launch_bounds__(256) void k_critic_value(const float* __restrict__ logits, int64_t ldl, int NB,
+                                                       const float* __restrict__ buckets, int rows, int H,
+                                                       float* __restrict__ V, float* __restrict__ v_last) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* lg = logits + (int64_t)row * ldl;
+    float mx = -3.0e38f;
+    for (int i = lane; i < NB; i += 64) mx = fmaxf(mx, lg[i]);
+    mx = group_max<64>(mx);
+    float se = 0.f, sb = 0.f;
+    for (int i = lane; i < NB; i += 64) {
+        const float e = expf(lg[i] - mx);
+        se += e;
+        sb = fmaf(e, buckets[i], sb);
+    }
+    se = group_sum<64>(se);
+    sb = group_sum<64>(sb);
+    if (lane == 0) {
+        const float v = symexp_f(sb / se);
+        V[row] = v;
+        if (v_last && (row % H) == H - 1) v_last[row / H] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------------
+struct ProblemSpec {
+    const float* X; int64_t ldx; const float* ln_g; const float* ln_b;
+    const float* W; int64_t ldw; const float* bias; const float* tab; int64_t ldt;
+    float* Y; int64_t ldy; int N, K;
+};
+
+static int check_problem(const ProblemSpec& s) {
+    DRM_REQUIRE(s.X && s.W && s.Y, DRM_EINVAL, "null pointer in linear problem");
+    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0, DRM_ENOTSUP, "K=%d must be a positive multiple of 32", s.K);
+    DRM_REQUIRE(s.N >= 1, DRM_EINVAL, "N=%d", s.N);
+    DRM_REQUIRE(aligned16(s.X) && aligned16(s.W) && s.ldx % 4 == 0 && s.ldw % 4 == 0, DRM_EINVAL,
+                "X/W must be 16-byte aligned with row strides a multiple of 4 floats");
+    DRM_REQUIRE(!s.ln_g || (s.ln_b && aligned16(s.ln_g) && aligned16(s.ln_b)), DRM_EINVAL, "bad LayerNorm pointers");
+    return DRM_OK;
+}
+
+static int launch_store(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents,
+                        int classes, hipStream_t stream) {
+    DRM_REQUIRE(np >= 1 && np <= MAX_PROBLEMS && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
+    LinLaunch L{};
+    int tiles = 0;
+    for (int i = 0; i < np; ++i) {
+        if (int rc = check_problem(specs[i])) return rc;
+        DRM_REQUIRE(!specs[i].tab || zidx, DRM_EINVAL, "gather table without indices");
+        LinProblem& p = L.p[i];
+        p.X = specs[i].X; p.ldx = specs[i].ldx; p.ln_g = specs[i].ln_g; p.ln_b = specs[i].ln_b;
+        p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.tab = specs[i].tab; p.ldt = specs[i].ldt;
+        p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.tile_begin = tiles;
+        tiles += (specs[i].N + 15) / 16;
+    }
+    L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
+    k_linear16<1, EPI_STORE><<<dim3(tiles, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{});
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+static int launch_gru(const ProblemSpec& spec, int M, const GruEpilogue& G, hipStream_t stream) {
+    if (int rc = check_problem(spec)) return rc;
+    DRM_REQUIRE(spec.N == 3 * G.D && G.D % 16 == 0, DRM_ENOTSUP, "GRU width %d", G.D);
+    LinLaunch L{};
+    LinProblem& p = L.p[0];
+    p.X = spec.X; p.ldx = spec.ldx; p.W = spec.W; p.ldw = spec.ldw; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
+    L.np = 1; L.M = M;
+    k_linear16<3, EPI_GRU><<<dim3(G.D / 16, (M + 15) / 16), dim3(256), 0, stream>>>(L, G, SampleEpilogue{});
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+static int launch_sample(const ProblemSpec& spec, int M, int latents, const SampleEpilogue& S, hipStream_t stream) {
+    if (int rc = check_problem(spec)) return rc;
+    DRM_REQUIRE(spec.N == latents * 32 && spec.bias, DRM_EINVAL, "sampling head must have N = 32*latents and a bias");
+    LinLaunch L{};
+    LinProblem& p = L.p[0];
+    p.X = spec.X; p.ldx = spec.ldx; p.ln_g = spec.ln_g; p.ln_b = spec.ln_b; p.W = spec.W; p.ldw = spec.ldw;
+    p.bias = spec.bias; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
+    L.np = 1; L.M = M;
+    k_linear16<2, EPI_SAMPLE><<<dim3(latents, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, S);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+static int check_dims(const drm_dims& d) {
+    DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
+    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0, DRM_ENOTSUP,
+                "D=%d and M=%d must be multiples of 32", d.D, d.M);
+    DRM_REQUIRE(d.L >= 1 && d.L <= 256, DRM_ENOTSUP, "latents=%d", d.L);
+    DRM_REQUIRE(d.A >= 1 && d.A <= 64, DRM_ENOTSUP, "actions=%d (max 64)", d.A);
+    DRM_REQUIRE(d.NB >= 1 && d.NB <= 256, DRM_ENOTSUP, "buckets=%d (max 256)", d.NB);
+    DRM_REQUIRE(d.E >= 1, DRM_EINVAL, "E=%d", d.E);
+    DRM_REQUIRE(d.M <= 8192, DRM_ENOTSUP, "M=%d (max 8192)", d.M);
+    return DRM_OK;
+}
+
+struct PackLayout {
+    size_t actor_zT, critic_zT, rew_zT, cont_zT, lin_zT, a_tab, total;   // offsets in floats
+};
+static PackLayout pack_layout(const drm_dims& d) {
+    PackLayout p{};
+    const size_t LK = (size_t)d.L * d.K;
+    size_t o = 0;
+    p.actor_zT = o; o += LK * d.M;
+    p.critic_zT = o; o += LK * d.M;
+    p.rew_zT = o; o += LK * d.M;
+    p.cont_zT = o; o += LK * d.M;
+    p.lin_zT = o; o += LK * d.D;
+    p.a_tab = o; o += (size_t)d.A * d.D;
+    p.total = (o + 3) & ~(size_t)3;
+    return p;
+}
+
+struct WsLayout {
+    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, total;   // offsets in floats
+};
+static WsLayout ws_layout(const drm_dims& d, int B, int H) {
+    WsLayout w{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+    w.a_pre[0] = take((size_t)B * d.M); w.a_pre[1] = take((size_t)B * d.M);
+    w.x = take((size_t)B * d.D);
+    w.gh = take((size_t)B * 3 * d.D);
+    w.d_pre[0] = take((size_t)B * d.M); w.d_pre[1] = take((size_t)B * d.M);
+    const size_t rows = (size_t)B * H;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) w.head[i][j] = take(rows * d.M);
+    w.critic_logits = take(rows * 256);
+    w.total = o;
+    return w;
+}
+
+static int check_mlp(const drm_mlp& m, int in_dim, int hidden, int out_dim, const char* name) {
+    DRM_REQUIRE(m.n_layers >= 1 && m.n_layers <= DRM_MAX_MLP_LAYERS, DRM_ENOTSUP, "%s: %d layers", name, m.n_layers);
+    DRM_REQUIRE(m.in_dim == in_dim && m.hidden == hidden && m.out_dim == out_dim, DRM_EINVAL,
+                "%s: dims (%d,%d,%d) expected (%d,%d,%d)", name, m.in_dim, m.hidden, m.out_dim, in_dim, hidden, out_dim);
+    for (int i = 0; i < m.n_layers; ++i)
+        DRM_REQUIRE(m.w[i] && m.b[i] && m.ln_g[i] && m.ln_b[i], DRM_EINVAL, "%s: null layer %d", name, i);
+    DRM_REQUIRE(m.head_w && m.head_b, DRM_EINVAL, "%s: null head", name);
+    return DRM_OK;
+}
+
+static int check_weights(const drm_imagine_weights& w) {
+    if (int rc = check_dims(w.dims)) return rc;
+    const drm_dims& d = w.dims;
+    const int S = d.D + d.L * d.K;
+    DRM_REQUIRE(w.a_emb && w.lin_w && w.lin_b && w.gru_w_ih && w.gru_w_hh && w.gru_b_ih && w.gru_b_hh && w.buckets,
+                DRM_EINVAL, "null sequence-model pointer");
+    if (int rc = check_mlp(w.dyn, d.D, d.M, d.L * d.K, "dyn")) return rc;
+    if (int rc = check_mlp(w.rew, S, d.M, 1, "rew")) return rc;
+    if (int rc = check_mlp(w.cont, S, d.M, 1, "cont")) return rc;
+    if (int rc = check_mlp(w.actor, S, d.M, d.A, "actor")) return rc;
+    if (int rc = check_mlp(w.critic, S, d.M, d.NB, "critic")) return rc;
+    return DRM_OK;
+}
+
+}  // namespace drm
+
+using namespace drm;
+
+extern "C" size_t drm_pack_imagine_bytes(const drm_dims* dims) {
+    if (!dims || check_dims(*dims) != DRM_OK) return 0;
+    return pack_layout(*dims).total * sizeof(float);
+}
+
+extern "C" int drm_pack_imagine(const drm_imagine_weights* w, float* pack_out, size_t pack_bytes, drm_stream_t stream) {
+    DRM_REQUIRE(w && pack_out, DRM_EINVAL, "null pointer");
+    if (int rc = check_weights(*w)) return rc;
+    const drm_dims& d = w->dims;
+    const PackLayout pl = pack_layout(d);
+    DRM_REQUIRE(pack_bytes >= pl.total * sizeof(float), DRM_EINVAL, "pack buffer too small");
+    DRM_REQUIRE(aligned16(pack_out), DRM_EINVAL, "pack buffer must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int LK = d.L * d.K, S = d.D + LK;
+    struct { const float* W; int64_t ldw; int col0; int nrows; size_t off; } jobs[5] = {
+        {w->actor.w[0], S, d.D, d.M, pl.actor_zT}, {w->critic.w[0], S, d.D, d.M, pl.critic_zT},
+        {w->rew.w[0], S, d.D, d.M, pl.rew_zT},     {w->cont.w[0], S, d.D, d.M, pl.cont_zT},
+        {w->lin_w, LK + d.E, 0, d.D, pl.lin_zT}};
+    for (auto& j : jobs) {
+        k_transpose_cols<<<dim3((LK + 31) / 32, (j.nrows + 31) / 32), dim3(256), 0, s>>>(j.W, j.ldw, j.col0, LK, j.nrows,
+                                                                                         pack_out + j.off);
+        DRM_LAUNCH_CHECK();
+    }
+    k_action_table<<<dim3((d.D + 255) / 256, d.A), dim3(256), 0, s>>>(w->lin_w, LK + d.E, LK, d.E, w->a_emb, d.A, d.D,
+                                                                       pack_out + pl.a_tab);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+extern "C" size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H) {
+    if (!dims || check_dims(*dims) != DRM_OK || B < 1 || H < 1) return 0;
+    return ws_layout(*dims, B, H).total * sizeof(float);
+}
+
+extern "C" int drm_fused_linear_f32(const drm_linear_args* a, drm_stream_t stream) {
+    DRM_REQUIRE(a, DRM_EINVAL, "null args");
+    DRM_REQUIRE(a->M >= 1, DRM_EINVAL, "M=%d", a->M);
+    DRM_REQUIRE(!a->table || (a->classes >= 1 && a->latents >= 1), DRM_EINVAL, "bad gather shape");
+    ProblemSpec s{a->X, a->ldx, a->ln_gamma, a->ln_beta, a->W, a->ldw, a->bias, a->table, a->ldt, a->Y, a->ldy, a->N, a->K};
+    return launch_store(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream);
+}
+
+extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
+    DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
+    if (int rc = check_weights(*w)) return rc;
+    const drm_dims& d = w->dims;
+    const int B = io->B, H = io->H, D = d.D, M = d.M, L = d.L, LK = d.L * d.K, S = D + LK;
+    DRM_REQUIRE(B >= 1 && H >= 1, DRM_EINVAL, "B=%d H=%d", B, H);
+    DRM_REQUIRE((int64_t)B * H < (1 << 30), DRM_ENOTSUP, "B*H too large");
+    DRM_REQUIRE(io->h0 && io->zidx0 && io->expo_a && io->expo_z && io->h_out && io->zidx_out && io->actions_out &&
+                    io->rewards_out && io->conts_out && io->values_out && io->v_last_out && io->lam_returns_out,
+                DRM_EINVAL, "null io pointer");
+    const PackLayout pl = pack_layout(d);
+    DRM_REQUIRE(w->pack && w->pack_bytes >= pl.total * sizeof(float), DRM_EINVAL, "weights not packed (drm_pack_imagine)");
+    const WsLayout wl = ws_layout(d, B, H);
+    DRM_REQUIRE(io->workspace && io->workspace_bytes >= wl.total * sizeof(float) && aligned16(io->workspace), DRM_EINVAL,
+                "workspace too small or misaligned: need %zu bytes", wl.total * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)io->workspace;
+    const float* pack = w->pack;
+    const float l1m = (float)log1p(-(double)d.unimix_eps);
+    const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
+    const float lea = (float)(log((double)d.unimix_eps) - log((double)d.A));
+
+    // gh for step 0
+    {
+        ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D};
+        if (int rc = launch_store(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+    }
+    for (int t = 0; t < H; ++t) {
+        const float* h_t = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D;
+        const int64_t ldh = t == 0 ? D : (int64_t)H * D;
+        const uint8_t* z_t = t == 0 ? io->zidx0 : io->zidx_out + (size_t)(t - 1) * L;
+        const int64_t ldz = t == 0 ? L : (int64_t)H * L;
+        // actor MLP
+        for (int i = 0; i < w->actor.n_layers; ++i) {
+            ProblemSpec p{};
+            if (i == 0) p = ProblemSpec{h_t, ldh, nullptr, nullptr, w->actor.w[0], S, w->actor.b[0], pack + pl.actor_zT, M,
+                                        ws + wl.a_pre[0], M, M, D};
+            else p = ProblemSpec{ws + wl.a_pre[(i - 1) & 1], M, w->actor.ln_g[i - 1], w->actor.ln_b[i - 1], w->actor.w[i], M,
+                                 w->actor.b[i], nullptr, 0, ws + wl.a_pre[i & 1], M, M, M};
+            if (int rc = launch_store(&p, 1, B, z_t, ldz, L, d.K, s)) return rc;
+        }
+        // actor head, action draw, GRU input row
+        {
+            const int last = w->actor.n_layers - 1;
+            ActorHeadArgs a{};
+            a.pre = ws + wl.a_pre[last & 1]; a.ldp = M;
+            a.ln_g = w->actor.ln_g[last]; a.ln_b = w->actor.ln_b[last];
+            a.head_w = w->actor.head_w; a.head_b = w->actor.head_b; a.M = M; a.A = d.A;
+            a.expo = io->expo_a + (size_t)t * B * d.A; a.lde = d.A;
+            a.forced = io->forced_actions ? io->forced_actions + t : nullptr; a.ldf = H;
+            a.log1m_eps = l1m; a.log_eps_over_a = lea;
+            a.zidx = z_t; a.ldz = ldz; a.latents = L; a.classes = d.K;
+            a.lin_zT = pack + pl.lin_zT; a.lin_b = w->lin_b; a.a_tab = pack + pl.a_tab; a.D = D;
+            a.x = ws + wl.x; a.ldxo = D;
+            a.a_used = io->actions_out + t; a.ldau = H;
+            a.a_sampled = io->actions_sampled_out ? io->actions_sampled_out + t : nullptr; a.ldas = H;
+            a.logp_out = io->actor_logp_out ? io->actor_logp_out + (size_t)t * d.A : nullptr; a.ldlp = (int64_t)H * d.A;
+            k_actor_head_x<<<dim3(B), dim3(256), (size_t)M * sizeof(float), s>>>(a);
+            DRM_LAUNCH_CHECK();
+        }
+        // GRU: gi = W_ih x, gates with the precomputed gh -> h_{t+1} written into h_out[:, t]
+        float* h_new = io->h_out + (size_t)t * D;
+        {
+            ProblemSpec p{ws + wl.x, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, h_new, (int64_t)H * D, 3 * D, D};
+            GruEpilogue G{w->gru_b_ih, ws + wl.gh, 3 * D, h_t, ldh, h_new, (int64_t)H * D, D};
+            if (int rc = launch_gru(p, B, G, s)) return rc;
+        }
+        // dyn layer 1 and (for the next step) gh = W_hh h_{t+1} + b_hh share their input
+        {
+            ProblemSpec p[2] = {
+                {h_new, (int64_t)H * D, nullptr, nullptr, w->dyn.w[0], D, w->dyn.b[0], nullptr, 0, ws + wl.d_pre[0], M, M, D},
+                {h_new, (int64_t)H * D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D}};
+            if (int rc = launch_store(p, t + 1 < H ? 2 : 1, B, nullptr, 0, 0, 0, s)) return rc;
+        }
+        for (int i = 1; i < w->dyn.n_layers; ++i) {
+            ProblemSpec p{ws + wl.d_pre[(i - 1) & 1], M, w->dyn.ln_g[i - 1], w->dyn.ln_b[i - 1], w->dyn.w[i], M, w->dyn.b[i],
+                          nullptr, 0, ws + wl.d_pre[i & 1], M, M, M};
+            if (int rc = launch_store(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+        }
+        // dyn head + unimix + Gumbel-argmax draw of z_{t+1}
+        {
+            const int last = w->dyn.n_layers - 1;
+            ProblemSpec p{ws + wl.d_pre[last & 1], M, w->dyn.ln_g[last], w->dyn.ln_b[last], w->dyn.head_w, M, w->dyn.head_b,
+                          nullptr, 0, nullptr, 0, LK, M};
+            p.Y = ws;  // unused by the sampling epilogue
+            SampleEpilogue E{};
+            E.expo = io->expo_z + (size_t)t * B * LK; E.lde = LK;
+            E.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; E.ldf = (int64_t)H * L;
+            E.idx_used = io->zidx_out + (size_t)t * L; E.ldu = (int64_t)H * L;
+            E.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; E.lds_ = (int64_t)H * L;
+            E.z_dense = io->z_out ? io->z_out + (size_t)t * LK : nullptr; E.ldzd = (int64_t)H * LK;
+            E.logits_out = io->prior_logits_out ? io->prior_logits_out + (size_t)t * LK : nullptr; E.ldlo = (int64_t)H * LK;
+            E.log1m_eps = l1m; E.log_eps_over_k = lek;
+            if (int rc = launch_sample(p, B, L, E, s)) return rc;
+        }
+    }
+
+    // ---- heads over all B*H imagined states ----
+    const int rows = B * H;
+    const drm_mlp* heads[3] = {&w->rew, &w->cont, &w->critic};
+    const size_t tabs[3] = {pl.rew_zT, pl.cont_zT, pl.critic_zT};
+    int depth_max = 0;
+    for (int i = 0; i < 3; ++i) depth_max = heads[i]->n_layers > depth_max ? heads[i]->n_layers : depth_max;
+    for (int dep = 0; dep <= depth_max; ++dep) {
+        ProblemSpec p[3];
+        int np = 0;
+        for (int i = 0; i < 3; ++i) {
+            const drm_mlp& m = *heads[i];
+            if (dep == 0) {
+                p[np++] = ProblemSpec{io->h_out, D, nullptr, nullptr, m.w[0], S, m.b[0], pack + tabs[i], M, ws + wl.head[i][0], M, M, D};
+            } else if (dep < m.n_layers) {
+                p[np++] = ProblemSpec{ws + wl.head[i][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.w[dep], M, m.b[dep],
+                                      nullptr, 0, ws + wl.head[i][dep & 1], M, M, M};
+            } else if (dep == m.n_layers && i == 2) {  // critic bucket logits
+                p[np++] = ProblemSpec{ws + wl.head[2][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.head_w, M, m.head_b,
+                                      nullptr, 0, ws + wl.critic_logits, 256, d.NB, M};
+            }
+        }
+        if (np == 0) continue;
+        if (int rc = launch_store(p, np, rows, io->zidx_out, L, L, d.K, s)) return rc;
+    }
+    {
+        ScalarHeadsArgs a{};
+        a.nh = 2; a.rows = rows; a.M = M;
+        for (int i = 0; i < 2; ++i) {
+            const drm_mlp& m = *heads[i];
+            const int last = m.n_layers - 1;
+            a.h[i] = ScalarHead{ws + wl.head[i][last & 1], M, m.ln_g[last], m.ln_b[last], m.head_w, m.head_b,
+                                i == 0 ? io->rewards_out : io->conts_out, nullptr, i == 0 ? 1 : 2};
+        }
+        k_scalar_heads<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(a);
+        DRM_LAUNCH_CHECK();
+    }
+    k_critic_value<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(ws + wl.critic_logits, 256, d.NB, w->buckets, rows, H,
+                                                              io->values_out, io->v_last_out);
+    DRM_LAUNCH_CHECK();
+    return drm_lambda_return(io->rewards_out, io->conts_out, io->values_out, io->v_last_out, io->lam_returns_out, B, H,
+                             io->gamma, io->lam, stream);
+}

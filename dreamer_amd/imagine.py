@@ -1,0 +1,177 @@
+"""Imagination block on the GPU: the no-grad part of an update between the world-model step and
+the actor / critic steps (lib/trainer.py:176-224) as one native call.
+
+    actor -> sample action -> prior RSSM step        (H times, B trajectories)
+    reward / continue heads, critic value            (once, over all B*H imagined states)
+    lambda-return                                    (reverse scan over H)
+
+The decoder is not evaluated: the reference computes it inside ``step`` and discards the result
+(lib/world_model.py:447, lib/trainer.py:192); it consumes no random numbers, so skipping it does not
+change any value.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as N
+from .world_model import WorldModelState
+
+
+def _mlp_struct(mlp, head, in_dim: int) -> N.drm_mlp:
+    linears = [m for m in mlp if isinstance(m, torch.nn.Linear)]
+    norms = [m for m in mlp if isinstance(m, torch.nn.LayerNorm)]
+    s = N.drm_mlp()
+    s.n_layers, s.in_dim, s.hidden, s.out_dim = len(linears), in_dim, linears[0].out_features, head.out_features
+    for i, (lin, ln) in enumerate(zip(linears, norms)):
+        s.w[i], s.b[i], s.ln_g[i], s.ln_b[i] = (lin.weight.data_ptr(), lin.bias.data_ptr(), ln.weight.data_ptr(),
+                                                ln.bias.data_ptr())
+    s.head_w, s.head_b = head.weight.data_ptr(), head.bias.data_ptr()
+    return s
+
+
+class ImagineEngine:
+    """Owns the packed gather tables and the workspace for one (world model, actor, critic) triple."""
+
+    def __init__(self, world_model, actor, critic):
+        self.wm, self.actor, self.critic = world_model, actor, critic
+        p = next(world_model.parameters())
+        if not p.is_cuda:
+            raise N.NativeError("ImagineEngine needs the models on a HIP device")
+        self.device = p.device
+        wm = world_model
+        self.dims = N.drm_dims(D=wm.hidden_size, L=wm.num_latents, K=wm.classes_per_latent,
+                               M=wm.dyn.mlp[0].out_features, A=wm.action_size, E=wm.seq.a_emb.embedding_dim,
+                               NB=critic.num_buckets, unimix_eps=wm.unimix_eps)
+        for m in list(wm.parameters()) + list(actor.parameters()) + list(critic.parameters()):
+            if m.dtype != torch.float32 or not m.is_contiguous():
+                raise N.NativeError("parameters must be contiguous fp32")
+        nbytes = N.lib().drm_pack_imagine_bytes(C.byref(self.dims))
+        if nbytes == 0:
+            raise N.NativeError(f"unsupported dimensions: {N.lib().drm_last_error().decode()}")
+        self.pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        self._ws = None
+        self._ws_key = None
+        self.repack()
+
+    def _weights(self) -> N.drm_imagine_weights:
+        wm, d = self.wm, self.dims
+        S = d.D + d.L * d.K
+        w = N.drm_imagine_weights()
+        w.dims = d
+        w.a_emb, w.lin_w, w.lin_b = wm.seq.a_emb.weight.data_ptr(), wm.seq.linear.weight.data_ptr(), wm.seq.linear.bias.data_ptr()
+        g = wm.seq.gru
+        w.gru_w_ih, w.gru_w_hh, w.gru_b_ih, w.gru_b_hh = (g.weight_ih.data_ptr(), g.weight_hh.data_ptr(),
+                                                         g.bias_ih.data_ptr(), g.bias_hh.data_ptr())
+        w.dyn = _mlp_struct(wm.dyn.mlp, wm.dyn.head, d.D)
+        w.rew = _mlp_struct(wm.rew.mlp, wm.rew.head, S)
+        w.cont = _mlp_struct(wm.cont.mlp, wm.cont.head, S)
+        w.actor = _mlp_struct(self.actor.mlp, self.actor.head, S)
+        w.critic = _mlp_struct(self.critic.mlp, self.critic.head, S)
+        w.buckets = self.critic.buckets.data_ptr()
+        w.pack, w.pack_bytes = self.pack.data_ptr(), self.pack.numel() * 4
+        return w
+
+    def repack(self) -> None:
+        """Rebuild the one-hot gather tables from the current weights (needed after optimiser steps)."""
+        w = self._weights()
+        N.check(N.lib().drm_pack_imagine(C.byref(w), self.pack.data_ptr(), self.pack.numel() * 4,
+                                         N.stream_ptr(self.device)), "drm_pack_imagine")
+
+    def _workspace(self, B: int, H: int) -> torch.Tensor:
+        if self._ws_key != (B, H):
+            nbytes = N.lib().drm_imagine_workspace_bytes(C.byref(self.dims), B, H)
+            self._ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=self.device)
+            self._ws_key = (B, H)
+        return self._ws
+
+    @torch.no_grad()
+    def run(self, start: WorldModelState, horizon: int, gamma: float, lam: float,
+            noise: Optional[Dict[str, torch.Tensor]] = None, forced_actions: Optional[torch.Tensor] = None,
+            forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
+            want_prior_logits: bool = False, want_sampled: bool = False, start_zidx: Optional[torch.Tensor] = None,
+            repack: bool = True) -> Dict[str, torch.Tensor]:
+        d, dev = self.dims, self.device
+        B, H = start.h.shape[0], int(horizon)
+        if repack:
+            self.repack()
+        h0 = start.h.detach().contiguous().float()
+        zidx0 = start_zidx if start_zidx is not None else N.onehot_to_index(start.z.detach().contiguous().float())
+        if noise is None:
+            noise = {"a": torch.empty(H, B, d.A, device=dev).exponential_(),
+                     "z": torch.empty(H, B, d.L, d.K, device=dev).exponential_()}
+        ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
+        assert ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K)
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {
+            "h": torch.empty(B, H, d.D, **f32), "zidx": torch.empty(B, H, d.L, dtype=torch.uint8, device=dev),
+            "actions": torch.empty(B, H, dtype=torch.int64, device=dev), "rewards": torch.empty(B, H, **f32),
+            "conts": torch.empty(B, H, **f32), "values": torch.empty(B, H, **f32), "v_last": torch.empty(B, **f32),
+            "lam_returns": torch.empty(B, H, **f32),
+        }
+        if want_dense_z:
+            out["z"] = torch.empty(B, H, d.L, d.K, **f32)
+        if want_logp:
+            out["actor_logp"] = torch.empty(B, H, d.A, **f32)
+        if want_prior_logits:
+            out["prior_logits"] = torch.empty(B, H, d.L, d.K, **f32)
+        if want_sampled:
+            out["zidx_sampled"] = torch.empty(B, H, d.L, dtype=torch.uint8, device=dev)
+            out["actions_sampled"] = torch.empty(B, H, dtype=torch.int64, device=dev)
+        ws = self._workspace(B, H)
+        io = N.drm_imagine_io()
+        io.B, io.H = B, H
+        io.h0, io.zidx0, io.expo_a, io.expo_z = h0.data_ptr(), zidx0.data_ptr(), ea.data_ptr(), ez.data_ptr()
+        io.forced_actions = N.ptr(forced_actions.contiguous() if forced_actions is not None else None)
+        io.forced_zidx = N.ptr(forced_zidx.contiguous() if forced_zidx is not None else None)
+        io.h_out, io.zidx_out, io.actions_out = out["h"].data_ptr(), out["zidx"].data_ptr(), out["actions"].data_ptr()
+        io.z_out = N.ptr(out.get("z"))
+        io.zidx_sampled_out, io.actions_sampled_out = N.ptr(out.get("zidx_sampled")), N.ptr(out.get("actions_sampled"))
+        io.actor_logp_out, io.prior_logits_out = N.ptr(out.get("actor_logp")), N.ptr(out.get("prior_logits"))
+        io.rewards_out, io.conts_out, io.values_out = (out["rewards"].data_ptr(), out["conts"].data_ptr(),
+                                                       out["values"].data_ptr())
+        io.v_last_out, io.lam_returns_out = out["v_last"].data_ptr(), out["lam_returns"].data_ptr()
+        io.gamma, io.lam = float(gamma), float(lam)
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        w = self._weights()
+        N.check(N.lib().drm_imagine_block_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_imagine_block_f32")
+        return out
+
+
+def imagine_eager(world_model, actor, critic, start: WorldModelState, horizon: int, gamma: float, lam: float):
+    """The same block with eager tensor ops, for models that live on a host device."""
+    from .utils import symexp
+    s = start
+    hs, zs, acts, rews, conts, logps = [], [], [], [], [], []
+    with torch.no_grad():
+        for _ in range(horizon):
+            dist = actor(s)
+            a = dist.sample()
+            s, info = world_model.step(s, a_prev_idx=a)
+            hs.append(s.h); zs.append(s.z); acts.append(a); logps.append(dist.logits)
+            rews.append(symexp(info["r_hat"].squeeze(-1)))
+            conts.append(torch.sigmoid(info["c_hat"].squeeze(-1)))
+        Hs = WorldModelState(h=torch.stack(hs, 1), z=torch.stack(zs, 1))
+        R, Cn = torch.stack(rews, 1), torch.stack(conts, 1)
+        V = critic.value(Hs)
+        v_last = critic.value(WorldModelState(h=hs[-1], z=zs[-1]))
+        ret = torch.zeros_like(V)
+        nxt = v_last
+        for t in reversed(range(horizon)):
+            nxt = R[:, t] + gamma * (1.0 - Cn[:, t]) * ((1.0 - lam) * V[:, t] + lam * nxt)
+            ret[:, t] = nxt
+    return {"h": Hs.h, "z": Hs.z, "actions": torch.stack(acts, 1), "rewards": R, "conts": Cn, "values": V,
+            "v_last": v_last, "lam_returns": ret, "actor_logp": torch.stack(logps, 1)}
+
+
+def imagine(world_model, actor, critic, start: WorldModelState, horizon: int, gamma: float, lam: float, **kw):
+    """Dispatch on the device of the start state: HIP tensors run the native block."""
+    if start.h.is_cuda:
+        eng = getattr(world_model, "_imagine_engine", None)
+        if eng is None or eng.actor is not actor or eng.critic is not critic:
+            eng = ImagineEngine(world_model, actor, critic)
+            object.__setattr__(world_model, "_imagine_engine", eng)
+        return eng.run(start, horizon, gamma, lam, **kw)
+    return imagine_eager(world_model, actor, critic, start, horizon, gamma, lam)

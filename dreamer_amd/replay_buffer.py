@@ -1,0 +1,76 @@
+"""Ring replay buffer with the reference's surface (lib/replay_buffer.py), stored in device memory.
+
+Start indices are drawn on the host with the global numpy generator, in the same call with the
+same arguments as the reference (lib/replay_buffer.py:55-62), so for a given ``np.random.seed`` the
+sampled sequences are the same.  On a HIP device the (B, T) gather runs as one kernel over the
+HBM-resident ring; on a host device it is the plain index gather.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+
+class ReplayBuffer:
+    def __init__(self, capacity: int, obs_shape: Tuple[int, ...], seq_len: int, device: torch.device) -> None:
+        self.capacity, self.obs_shape, self.seq_len = int(capacity), tuple(obs_shape), int(seq_len)
+        self.device = torch.device(device)
+        self.observations = torch.zeros((self.capacity, *self.obs_shape), dtype=torch.uint8, device=self.device)
+        self.actions = torch.zeros(self.capacity, dtype=torch.long, device=self.device)
+        self.rewards = torch.zeros(self.capacity, dtype=torch.float32, device=self.device)
+        self.continues = torch.zeros(self.capacity, dtype=torch.bool, device=self.device)
+        self.idx, self.full = 0, False
+
+    def __len__(self) -> int:
+        return self.capacity if self.full else self.idx
+
+    def store(self, obs: np.ndarray, action: int, reward: float, cont: bool) -> None:
+        i = self.idx
+        self.observations[i].copy_(torch.as_tensor(obs, dtype=torch.uint8), non_blocking=True)
+        self.actions[i] = int(action)
+        self.rewards[i] = float(reward)
+        self.continues[i] = bool(cont)
+        self.idx = (i + 1) % self.capacity
+        self.full = self.full or self.idx == 0
+
+    def store_many(self, obs, actions, rewards, conts) -> None:
+        """Append n transitions at once (same final state as n ``store`` calls)."""
+        n = len(actions)
+        pos = (self.idx + np.arange(n)) % self.capacity
+        pos_t = torch.as_tensor(pos, device=self.device)
+        self.observations[pos_t] = torch.as_tensor(obs, dtype=torch.uint8).to(self.device)
+        self.actions[pos_t] = torch.as_tensor(actions, dtype=torch.long).to(self.device)
+        self.rewards[pos_t] = torch.as_tensor(rewards, dtype=torch.float32).to(self.device)
+        self.continues[pos_t] = torch.as_tensor(conts, dtype=torch.bool).to(self.device)
+        self.full = self.full or self.idx + n >= self.capacity
+        self.idx = (self.idx + n) % self.capacity
+
+    def draw_starts(self, batch_size: int) -> np.ndarray:
+        assert len(self) >= self.seq_len, "Not enough data to sample."
+        if self.full:
+            return np.random.randint(0, self.capacity, size=batch_size, dtype=np.int64)
+        last = self.idx - self.seq_len
+        if last < 0:
+            raise RuntimeError("Not enough data to sample the requested sequence length.")
+        return np.random.randint(0, last + 1, size=batch_size, dtype=np.int64)
+
+    def gather(self, starts: np.ndarray, want_f32: bool = False) -> Dict[str, torch.Tensor]:
+        T = self.seq_len
+        if self.device.type == "cuda":
+            from . import _native
+            st = torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)).to(self.device, non_blocking=True)
+            o, a, r, c, f = _native.seq_gather(self.observations, self.actions, self.rewards, self.continues, st, T,
+                                               want_f32)
+        else:
+            rows = torch.from_numpy((starts[:, None] + np.arange(T, dtype=np.int64)[None, :]) % self.capacity)
+            o, a, r, c = self.observations[rows], self.actions[rows], self.rewards[rows], self.continues[rows]
+            f = o.float() / 255.0 if want_f32 else None
+        out = {"observations": o, "actions": a, "rewards": r, "continues": c}
+        if want_f32:
+            out["observations_f32"] = f
+        return out
+
+    def sample(self, batch_size: int, want_f32: bool = False) -> Dict[str, torch.Tensor]:
+        return self.gather(self.draw_starts(batch_size), want_f32)

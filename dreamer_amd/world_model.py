@@ -1,0 +1,279 @@
+"""Categorical RSSM world model with the reference's class / method / state-dict surface
+(lib/world_model.py of ProfessorNova/Dreamer), restructured around the MI355X hot path.
+
+What is the same: module and parameter names (``seq.a_emb``, ``seq.linear``, ``seq.norm``,
+``seq.gru``, ``enc.conv.N``, ``enc.fc.0``, ``dyn.mlp.N``, ``dyn.head``, ``rew.*``, ``cont.*``,
+``dec.fc.0``, ``dec.deconv.N``), constructor arguments, ``init_state`` / ``step`` / ``loss``
+signatures and return values, and every numerical quirk (``seq.norm`` exists but is never
+applied, lib/world_model.py:35 vs :69-71).
+
+What is different: ``loss`` does not run T whole steps.  Only the recurrence
+``(h, z, a, c) -> GRU -> posterior logits -> z`` is sequential; the encoder convolutions are
+hoisted over all B*T frames before it and the prior MLP, reward / continue heads, decoder and the
+three loss terms are evaluated once over all B*T states after it (same values; the reference's
+per-step ``.mean()`` summed over t and divided by T equals the mean over all (b, t)).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .utils import log_unimix, symlog
+
+
+@dataclass
+class WorldModelState:
+    h: torch.Tensor  # (B, hidden) or (B, T, hidden)
+    z: torch.Tensor  # (B, L, K) one-hot, or (B, T, L, K)
+
+
+def _norm_act_mlp(in_dim: int, width: int, depth: int) -> nn.Sequential:
+    """depth x (Linear, LayerNorm, SiLU), laid out so that state-dict keys are mlp.{0,1,3,4,...}."""
+    mods = []
+    for i in range(depth):
+        mods += [nn.Linear(in_dim if i == 0 else width, width), nn.LayerNorm(width), nn.SiLU()]
+    return nn.Sequential(*mods)
+
+
+def hard_sample(log_probs: torch.Tensor, expo: Optional[torch.Tensor] = None):
+    """Straight-through Gumbel-softmax draw (tau = 1, hard): returns (z, y_soft, idx).
+
+    ``expo`` is the Exp(1) tensor torch's gumbel_softmax would draw; when None it is drawn here
+    from the global generator exactly as ``F.gumbel_softmax`` does.
+    """
+    if expo is None:
+        expo = torch.empty_like(log_probs, memory_format=torch.legacy_contiguous_format).exponential_()
+    y = torch.softmax(log_probs - expo.log(), dim=-1)
+    idx = y.max(dim=-1, keepdim=True)[1]
+    hard = torch.zeros_like(y).scatter_(-1, idx, 1.0)
+    return hard - y.detach() + y, y, idx.squeeze(-1)
+
+
+class SequenceModel(nn.Module):
+    """h_t = GRU(Linear(cat[z_{t-1}, emb(a_{t-1})]), h_{t-1}) with episode-boundary resets."""
+
+    def __init__(self, action_size: int, num_latents: int = 32, classes_per_latent: int = 32, hidden_size: int = 512):
+        super().__init__()
+        self.a_emb = nn.Embedding(action_size, 64)
+        self.linear = nn.Linear(num_latents * classes_per_latent + 64, hidden_size)
+        self.norm = nn.LayerNorm(hidden_size)  # present in the reference's state dict, never applied
+        self.act = nn.SiLU()
+        self.gru = nn.GRUCell(hidden_size, hidden_size)
+
+    def forward(self, h_prev, z_prev, a_prev_idx, c_prev=None, expo_reset=None):
+        emb = self.a_emb(a_prev_idx)
+        if c_prev is not None:
+            keep = c_prev.view(-1, 1, 1)
+            fresh, _, _ = hard_sample(torch.full_like(z_prev, 1.0 / z_prev.size(-1)), expo_reset)
+            h_prev = h_prev * c_prev
+            z_prev = z_prev * keep + (1.0 - keep) * fresh
+            emb = emb * c_prev
+        x = self.linear(torch.cat([z_prev.flatten(1), emb], dim=-1))
+        return self.gru(x, h_prev)
+
+
+def _conv_tower(channels, spatial, transpose: bool):
+    """Conv(k4,s2,p1) + LayerNorm[C,H,W] + SiLU per stage; spatial[i] is the OUTPUT size of stage i."""
+    mods = []
+    conv = nn.ConvTranspose2d if transpose else nn.Conv2d
+    for i in range(len(channels) - 1):
+        mods += [conv(channels[i], channels[i + 1], 4, stride=2, padding=1),
+                 nn.LayerNorm([channels[i + 1], spatial[i][0], spatial[i][1]]), nn.SiLU()]
+    return mods
+
+
+class Encoder(nn.Module):
+    """Posterior logits from cat[conv(x_t), h_t]."""
+
+    def __init__(self, obs_shape, num_latents=32, classes_per_latent=32, hidden_size=512, base_cnn_channels=32):
+        super().__init__()
+        C, H, W = obs_shape
+        assert H % 16 == 0 and W % 16 == 0, "H and W must be divisible by 16"
+        self.C, self.H, self.W = C, H, W
+        self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
+        c = base_cnn_channels
+        sizes = [(H >> s, W >> s) for s in (1, 2, 3, 4)]
+        self.conv = nn.Sequential(*_conv_tower([C, c, 2 * c, 4 * c, 8 * c], sizes, False), nn.Flatten())
+        self.conv_out_size = 8 * c * (H // 16) * (W // 16)
+        self.fc = nn.Sequential(nn.Linear(self.conv_out_size + hidden_size, num_latents * classes_per_latent))
+
+    def forward(self, x_t, h_t):
+        B, C, H, W = x_t.shape
+        assert (C, H, W) == (self.C, self.H, self.W), f"Got {(C, H, W)}, expected {(self.C, self.H, self.W)}"
+        feat = torch.cat([self.conv(x_t), h_t], dim=-1)
+        return self.fc(feat).view(-1, self.num_latents, self.classes_per_latent)
+
+
+class DynamicsPredictor(nn.Module):
+    """Prior logits from h_t."""
+
+    def __init__(self, hidden_size=512, num_latents=32, classes_per_latent=32, mlp_hidden_units=512, mlp_layers=3):
+        super().__init__()
+        self.mlp = _norm_act_mlp(hidden_size, mlp_hidden_units, mlp_layers)
+        self.head = nn.Linear(mlp_hidden_units, num_latents * classes_per_latent)
+        self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
+
+    def forward(self, h_t):
+        return self.head(self.mlp(h_t)).view(-1, self.num_latents, self.classes_per_latent)
+
+
+class _ScalarHead(nn.Module):
+    def __init__(self, width_h, num_latents, classes_per_latent, mlp_hidden_units, mlp_layers):
+        super().__init__()
+        self.mlp = _norm_act_mlp(width_h + num_latents * classes_per_latent, mlp_hidden_units, mlp_layers)
+        self.head = nn.Linear(mlp_hidden_units, 1)
+        self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
+
+    def forward(self, h_t, z_t):
+        return self.head(self.mlp(torch.cat([h_t, z_t.reshape(h_t.size(0), -1)], dim=-1)))
+
+
+class RewardPredictor(_ScalarHead):
+    def __init__(self, hidden_size=512, num_latents=32, classes_per_latent=32, mlp_hidden_units=512, mlp_layers=3):
+        super().__init__(hidden_size, num_latents, classes_per_latent, mlp_hidden_units, mlp_layers)
+
+
+class ContinuePredictor(_ScalarHead):
+    def __init__(self, h_dim=512, num_latents=32, classes_per_latent=32, mlp_hidden_units=512, mlp_layers=3):
+        super().__init__(h_dim, num_latents, classes_per_latent, mlp_hidden_units, mlp_layers)
+
+
+class Decoder(nn.Module):
+    """Image reconstruction from cat[h_t, z_t]."""
+
+    def __init__(self, obs_shape, num_latents=32, classes_per_latent=32, hidden_size=512, base_cnn_channels=32):
+        super().__init__()
+        C, H, W = obs_shape
+        assert H % 16 == 0 and W % 16 == 0, "H and W must be divisible by 16"
+        self.C, self.H, self.W = C, H, W
+        self.base_h, self.base_w = H // 16, W // 16
+        self.cnn_multiplier = c = base_cnn_channels
+        self.fc = nn.Sequential(nn.Linear(hidden_size + num_latents * classes_per_latent, 8 * c * self.base_h * self.base_w),
+                                nn.SiLU())
+        sizes = [(self.base_h << s, self.base_w << s) for s in (1, 2, 3)]
+        self.deconv = nn.Sequential(*_conv_tower([8 * c, 4 * c, 2 * c, c], sizes, True),
+                                    nn.ConvTranspose2d(c, C, 4, stride=2, padding=1), nn.Sigmoid())
+
+    def forward(self, h_t, z_t):
+        B = h_t.size(0)
+        seed = self.fc(torch.cat([h_t, z_t.reshape(B, -1)], dim=-1))
+        img = self.deconv(seed.view(B, 8 * self.cnn_multiplier, self.base_h, self.base_w))
+        assert img.shape == (B, self.C, self.H, self.W)
+        return img
+
+
+class WorldModel(nn.Module):
+    def __init__(self, obs_shape, action_size: int, num_latents: int = 32, classes_per_latent: int = 32,
+                 hidden_size: int = 512, base_cnn_channels: int = 32, mlp_hidden_units: int = 512,
+                 free_bits: float = 1.0, beta_pred: float = 1.0, beta_dyn: float = 0.5, beta_rep: float = 0.1,
+                 unimix_eps: float = 0.01):
+        super().__init__()
+        self.obs_shape, self.action_size, self.hidden_size = obs_shape, action_size, hidden_size
+        self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
+        self.free_bits, self.unimix_eps = free_bits, unimix_eps
+        self.beta_pred, self.beta_dyn, self.beta_rep = beta_pred, beta_dyn, beta_rep
+        lk = dict(num_latents=num_latents, classes_per_latent=classes_per_latent)
+        self.seq = SequenceModel(action_size=action_size, hidden_size=hidden_size, **lk)
+        self.enc = Encoder(obs_shape=obs_shape, hidden_size=hidden_size, base_cnn_channels=base_cnn_channels, **lk)
+        self.dyn = DynamicsPredictor(hidden_size=hidden_size, mlp_hidden_units=mlp_hidden_units, mlp_layers=3, **lk)
+        self.rew = RewardPredictor(hidden_size=hidden_size, mlp_hidden_units=mlp_hidden_units, mlp_layers=3, **lk)
+        self.cont = ContinuePredictor(h_dim=hidden_size, mlp_hidden_units=mlp_hidden_units, mlp_layers=3, **lk)
+        self.dec = Decoder(obs_shape=obs_shape, hidden_size=hidden_size, base_cnn_channels=base_cnn_channels, **lk)
+        for head in (self.rew.head, self.cont.head):  # zero-init heads, lib/world_model.py:398-401
+            nn.init.zeros_(head.weight)
+            nn.init.zeros_(head.bias)
+
+    # ------------------------------------------------------------------ single steps (any device, eager)
+    @torch.no_grad()
+    def init_state(self, batch_size: int, device=None, dtype=None, expo: Optional[torch.Tensor] = None) -> WorldModelState:
+        h0 = torch.zeros(batch_size, self.hidden_size, device=device, dtype=dtype)
+        flat = torch.full((batch_size, self.num_latents, self.classes_per_latent), 1.0 / self.classes_per_latent,
+                          device=device, dtype=dtype)
+        z0, _, _ = hard_sample(flat, expo)
+        return WorldModelState(h=h0, z=z0)
+
+    def _sample_z(self, logits: torch.Tensor, expo: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return hard_sample(log_unimix(logits, self.unimix_eps, dim=-1), expo)[0]
+
+    def step(self, state_prev: WorldModelState, a_prev_idx: torch.Tensor, x_cur: Optional[torch.Tensor] = None,
+             c_prev: Optional[torch.Tensor] = None) -> Tuple[WorldModelState, Dict[str, Any]]:
+        """One RSSM step: posterior when ``x_cur`` is given, prior otherwise.  Same outputs as the
+        reference's step (lib/world_model.py:415-457), heads and decoder included."""
+        h = self.seq(state_prev.h, state_prev.z, a_prev_idx, c_prev)
+        post = self.enc(x_cur, h) if x_cur is not None else None
+        prior = self.dyn(h)
+        z = self._sample_z(post if post is not None else prior)
+        info = {"prior_logits": prior, "post_logits": post, "r_hat": self.rew(h, z), "c_hat": self.cont(h, z),
+                "x_hat": self.dec(h, z)}
+        return WorldModelState(h=h, z=z), info
+
+    # ------------------------------------------------------------------ loss terms
+    def _kl_loss(self, q_logits: torch.Tensor, p_logits: torch.Tensor) -> torch.Tensor:
+        lq = log_unimix(q_logits, self.unimix_eps, dim=-1)
+        lp = log_unimix(p_logits, self.unimix_eps, dim=-1)
+        per_latent = (lq.exp() * (lq - lp)).sum(dim=-1)
+        return per_latent.clamp_min(self.free_bits / float(self.num_latents)).sum(dim=-1)
+
+    @staticmethod
+    def _prediction_loss(x_true, x_hat, r_true, r_hat, c_true, c_hat) -> torch.Tensor:
+        image = 0.5 * (x_hat - x_true).pow(2).mean(dim=(-3, -2, -1))
+        reward = 0.5 * (r_hat - symlog(r_true)).pow(2).mean(dim=-1)
+        cont = F.binary_cross_entropy_with_logits(c_hat, c_true, reduction="none").squeeze(-1)
+        return image + reward + cont
+
+    def _dynamics_loss(self, post_logits, prior_logits) -> torch.Tensor:
+        return self._kl_loss(post_logits.detach(), prior_logits)
+
+    def _representation_loss(self, post_logits, prior_logits) -> torch.Tensor:
+        return self._kl_loss(post_logits, prior_logits.detach())
+
+    # ------------------------------------------------------------------ observe: sequence loss
+    def observe(self, obs, actions, continues, init_state: Optional[WorldModelState] = None,
+                noise: Optional[Dict[str, torch.Tensor]] = None):
+        """Posterior rollout over a replayed (B, T) batch.
+
+        Returns (h (B,T,D), z (B,T,L,K) straight-through one-hot, post_logits (B,T,L,K), last state).
+        ``noise`` holds the Exp(1) draws: ``init`` (B,L,K) (unused when init_state is given),
+        ``reset`` and ``z`` (T,B,L,K); drawn from the global generator when None.
+        """
+        from .observe import observe_scan
+        B, T = obs.shape[:2]
+        L, K = self.num_latents, self.classes_per_latent
+        dev, dt = obs.device, obs.dtype
+        if noise is None:
+            noise = {"reset": torch.empty(T, B, L, K, device=dev, dtype=dt).exponential_(),
+                     "z": torch.empty(T, B, L, K, device=dev, dtype=dt).exponential_()}
+            if init_state is None:
+                noise["init"] = torch.empty(B, L, K, device=dev, dtype=dt).exponential_()
+        state = init_state if init_state is not None else self.init_state(B, device=dev, dtype=dt, expo=noise["init"])
+        a_prev = torch.roll(actions, 1, dims=1)
+        a_prev[:, 0] = 0
+        c = continues.to(dt)
+        c_prev = torch.cat([torch.ones(B, 1, device=dev, dtype=dt), c[:, :-1]], dim=1)  # (B,T)
+        fc = self.enc.fc[0]
+        n_conv = self.enc.conv_out_size
+        feat = self.enc.conv(obs.reshape(B * T, *obs.shape[2:]))
+        e_part = F.linear(feat, fc.weight[:, :n_conv], fc.bias).view(B, T, L * K)
+        return observe_scan(self, e_part, a_prev, c_prev, noise["reset"], noise["z"], state)
+
+    def loss(self, obs, actions, rewards, continues, init_state: Optional[WorldModelState] = None,
+             noise: Optional[Dict[str, torch.Tensor]] = None):
+        """World-model loss over a (B, T) batch; same value and gradients as lib/world_model.py:530-603."""
+        B, T = obs.shape[:2]
+        L, K = self.num_latents, self.classes_per_latent
+        h, z, post, last = self.observe(obs, actions, continues, init_state, noise)
+        hf, zf = h.reshape(B * T, -1), z.reshape(B * T, L, K)
+        prior = self.dyn(hf)
+        postf = post.reshape(B * T, L, K)
+        pred = self._prediction_loss(obs.reshape(B * T, *obs.shape[2:]), self.dec(hf, zf),
+                                     rewards.reshape(B * T, 1), self.rew(hf, zf),
+                                     continues.to(obs.dtype).reshape(B * T, 1), self.cont(hf, zf)).mean()
+        dyn = self._dynamics_loss(postf, prior).mean()
+        rep = self._representation_loss(postf, prior).mean()
+        total = self.beta_pred * pred + self.beta_dyn * dyn + self.beta_rep * rep
+        return total, {"total_loss": total, "pred_loss": pred, "dyn_loss": dyn, "rep_loss": rep, "state": last,
+                       "h": h, "post_logits": post, "prior_logits": prior.view(B, T, L, K)}

@@ -1,0 +1,193 @@
+/*
+ * dreamer_amd.h — C ABI of libdreamer_amd.so: gfx950 (MI355X) HIP kernels for the Dreamer
+ * hot path (RSSM imagine/observe steps, straight-through categorical sampling, lambda-return
+ * scan, replay sequence gather).
+ *
+ * The reference (ProfessorNova/Dreamer) has no FFI layer: its boundary is the Python
+ * class/method surface of lib/world_model.py, lib/actor.py, lib/critic.py,
+ * lib/replay_buffer.py and lib/trainer.py.  Each entry point below names the reference lines
+ * whose arithmetic it replaces; the Python package `dreamer_amd` calls these through ctypes
+ * from inside methods with the reference's names and signatures.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise;
+ *   - all tensors are dense row-major fp32 unless said otherwise; indices are int64 or uint8
+ *     as stated; "rows" always means independent trajectories (batch rows);
+ *   - every call enqueues on the given hipStream_t (passed as void*) and returns without
+ *     synchronising; nothing is allocated or freed: scratch comes in as a workspace whose size
+ *     the matching *_bytes() query returns;
+ *   - return value: 0 on success, a negative DRM_E* code otherwise (never throws);
+ *     drm_last_error() returns a thread-local message for the last failure;
+ *   - noise enters as explicit Exp(1) tensors ("expo"), in the order the reference consumes its
+ *     generator (F.gumbel_softmax: g = -log(E); torch.multinomial: argmax(p / E)).
+ */
+#ifndef DREAMER_AMD_H
+#define DREAMER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRM_OK 0
+#define DRM_EINVAL (-22)   /* bad shape / null pointer / misaligned pointer / workspace too small */
+#define DRM_ENOTSUP (-95)  /* dimension outside what the kernels are built for */
+#define DRM_EHIP (-5)      /* a HIP runtime call failed */
+#define DRM_EARCH (-19)    /* the current device is not gfx950 */
+
+#define DRM_MAX_MLP_LAYERS 4
+
+typedef void* drm_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int drm_version(void);
+const char* drm_last_error(void);
+/* 0 if the current HIP device is gfx950, DRM_EARCH otherwise. */
+int drm_arch_ok(void);
+
+/* ---- lambda-return scan: lib/trainer.py:217-224 --------------------------------------------
+ * ret[b,t] = R[b,t] + gamma*(1 - C[b,t])*((1-lam)*V[b,t] + lam*ret[b,t+1]),  ret[b,H] = V_last[b].
+ * R, C, V, out: (B,H) with t contiguous; V_last: (B).  gamma and lam are the Python floats of
+ * lib/config.py:36-37; they are rounded to fp32 the way torch rounds Python scalars that meet an
+ * fp32 tensor ((float)gamma, (float)(1.0 - lam), (float)lam), every product and sum is rounded
+ * separately (no fused multiply-add), so the result is bit-identical to the eager fp32 loop. */
+int drm_lambda_return(const float* R, const float* C, const float* V, const float* V_last,
+                      float* out, int64_t B, int32_t H, double gamma, double lam, drm_stream_t stream);
+
+/* ---- replay sequence gather: lib/replay_buffer.py:64-78 (+ lib/trainer.py:163) --------------
+ * The ring storage lives in device memory.  For b < B, t < T: src = (starts[b] + t) % capacity;
+ * obs_out[b,t,:] = obs[src,:] (frame_bytes each), likewise actions (int64), rewards (f32),
+ * continues (1 byte bool).  obs_f32_out, when not NULL, also receives float(obs)/255.0f
+ * (lib/trainer.py:163).  frame_bytes must be a multiple of 16 and all obs pointers 16-byte
+ * aligned.  starts is a device pointer to B int64 values, each in [0, capacity). */
+typedef struct drm_ring {
+    const uint8_t* observations; /* (capacity, frame_bytes) */
+    const int64_t* actions;      /* (capacity) */
+    const float* rewards;        /* (capacity) */
+    const uint8_t* continues;    /* (capacity) bool bytes */
+    int64_t capacity;
+    int64_t frame_bytes;
+} drm_ring;
+int drm_seq_gather(const drm_ring* ring, const int64_t* starts, int32_t B, int32_t T,
+                   uint8_t* obs_out, int64_t* actions_out, float* rewards_out, uint8_t* continues_out,
+                   float* obs_f32_out, drm_stream_t stream);
+
+/* ---- straight-through categorical sampling: lib/world_model.py:459-461, lib/utils.py:20-31 --
+ * rows = B*L independent categoricals over K = 32 classes.
+ *   lp = log_unimix(logits, eps)   (eps < 0: lp = logits, the form lib/world_model.py:59,:412 use)
+ *   y  = softmax(lp - log(expo));  idx = argmax (first max on ties);  z = one_hot(idx).
+ * Any of z_out (rows,K) f32, idx_out (rows) u8, y_out (rows,K) f32 may be NULL. */
+int drm_sample_categorical_st(const float* logits, const float* expo, int64_t rows, int32_t K,
+                              float unimix_eps, float* z_out, uint8_t* idx_out, float* y_out,
+                              drm_stream_t stream);
+
+/* argmax over the last dim of a dense (rows,K) one-hot tensor -> uint8 indices. */
+int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint8_t* idx_out, drm_stream_t stream);
+
+/* ---- fused linear block (building block of every step below) --------------------------------
+ * Y[m, n] = bias[n] + sum_k f(X)[m,k] * W[n,k] + sum_l table[(l*classes + zidx[m,l]), n]
+ *   f = identity, or SiLU(LayerNorm(X row; ln_gamma, ln_beta, eps 1e-5)) when ln_gamma != NULL
+ *   (the Linear -> LayerNorm -> SiLU blocks of lib/world_model.py:153-160 etc., with the
+ *   normalisation applied by the consumer of the raw pre-activations);
+ *   the table term (optional) is the one-hot part of a Linear over cat[h, z_flat]
+ *   (lib/world_model.py:213-215) written as a row gather.
+ * W is (N,K) row-major with row stride ldw (torch Linear layout).  K % 32 == 0. */
+typedef struct drm_linear_args {
+    const float* X; int64_t ldx;
+    const float* ln_gamma; const float* ln_beta;
+    const float* W; int64_t ldw;
+    const float* bias;
+    const float* table; int64_t ldt;   /* (latents*classes, ldt) or NULL */
+    const uint8_t* zidx; int64_t ldz;  /* (M, latents) */
+    int32_t latents, classes;
+    float* Y; int64_t ldy;
+    int32_t M, N, K;
+} drm_linear_args;
+int drm_fused_linear_f32(const drm_linear_args* args, drm_stream_t stream);
+
+/* ---- imagination block: lib/trainer.py:176-224 ----------------------------------------------
+ * actor -> sample action -> WorldModel.step(prior) for H steps, then reward / continue heads,
+ * critic value and the lambda-return, for B independent trajectories.  The decoder call of
+ * lib/world_model.py:447 is not executed (its output is discarded by lib/trainer.py:192 and it
+ * consumes no random numbers). */
+typedef struct drm_mlp {
+    int32_t n_layers;  /* Linear+LayerNorm+SiLU blocks */
+    int32_t in_dim, hidden, out_dim;
+    const float* w[DRM_MAX_MLP_LAYERS];    /* (hidden, in) torch layout */
+    const float* b[DRM_MAX_MLP_LAYERS];
+    const float* ln_g[DRM_MAX_MLP_LAYERS];
+    const float* ln_b[DRM_MAX_MLP_LAYERS];
+    const float* head_w;  /* (out_dim, hidden) */
+    const float* head_b;
+} drm_mlp;
+
+typedef struct drm_dims {
+    int32_t D;   /* recurrent width (hidden_size) */
+    int32_t L;   /* latents */
+    int32_t K;   /* classes per latent: must be 32 */
+    int32_t M;   /* mlp_hidden_units */
+    int32_t A;   /* actions (<= 64) */
+    int32_t E;   /* action embedding width (64) */
+    int32_t NB;  /* critic buckets (<= 256) */
+    float unimix_eps;
+} drm_dims;
+
+typedef struct drm_imagine_weights {
+    drm_dims dims;
+    const float* a_emb;   /* seq.a_emb.weight (A,E) */
+    const float* lin_w;   /* seq.linear.weight (D, L*K+E) */
+    const float* lin_b;
+    const float* gru_w_ih; /* (3D, D), gates r,z,n */
+    const float* gru_w_hh;
+    const float* gru_b_ih;
+    const float* gru_b_hh;
+    drm_mlp dyn;    /* D -> M x3 -> L*K */
+    drm_mlp rew;    /* D+L*K -> M x3 -> 1 */
+    drm_mlp cont;   /* D+L*K -> M x3 -> 1 */
+    drm_mlp actor;  /* D+L*K -> M xn -> A */
+    drm_mlp critic; /* D+L*K -> M xn -> NB */
+    const float* buckets; /* (NB) */
+    const float* pack;    /* written by drm_pack_imagine */
+    size_t pack_bytes;
+} drm_imagine_weights;
+
+/* Bytes of the packed-table buffer for these dims (one-hot gather tables: the z-columns of the
+ * first Linear of actor/critic/rew/cont and of seq.linear, transposed, plus the action table
+ * seq.linear[:, L*K:] @ a_emb^T).  Must be re-packed after every optimiser step. */
+size_t drm_pack_imagine_bytes(const drm_dims* dims);
+int drm_pack_imagine(const drm_imagine_weights* w, float* pack_out, size_t pack_bytes, drm_stream_t stream);
+
+typedef struct drm_imagine_io {
+    int32_t B, H;
+    const float* h0;               /* (B,D) start recurrent state */
+    const uint8_t* zidx0;          /* (B,L) start latent class indices */
+    const float* expo_a;           /* (H,B,A) Exp(1) for the action draw of each step */
+    const float* expo_z;           /* (H,B,L,K) Exp(1) for the latent draw of each step */
+    const int64_t* forced_actions; /* (B,H) or NULL: use these instead of the sampled actions */
+    const uint8_t* forced_zidx;    /* (B,H,L) or NULL: use these instead of the sampled latents */
+    float* h_out;                  /* (B,H,D) */
+    uint8_t* zidx_out;             /* (B,H,L) latents fed forward (forced ones if given) */
+    uint8_t* zidx_sampled_out;     /* (B,H,L) or NULL: what the sampler drew */
+    float* z_out;                  /* (B,H,L,K) dense one-hot or NULL */
+    int64_t* actions_out;          /* (B,H) actions fed forward */
+    int64_t* actions_sampled_out;  /* (B,H) or NULL */
+    float* actor_logp_out;         /* (B,H,A) normalised mixed log-probs or NULL */
+    float* prior_logits_out;       /* (B,H,L,K) or NULL */
+    float* rewards_out;            /* (B,H) symexp(r_hat) */
+    float* conts_out;              /* (B,H) sigmoid(c_hat) */
+    float* values_out;             /* (B,H) critic value */
+    float* v_last_out;             /* (B) */
+    float* lam_returns_out;        /* (B,H) */
+    double gamma, lam;
+    void* workspace; size_t workspace_bytes;
+} drm_imagine_io;
+
+size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H);
+int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DREAMER_AMD_H */
