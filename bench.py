@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the Dreamer hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload imagine16|imagine4096]
+
+One "step" is one imagination block (lib/trainer.py:176-224 of the reference: actor -> action
+draw -> prior RSSM step, H = 15 times; reward / continue heads; critic value; lambda-return) for
+B start states, including the generation of its Exp(1) noise.  Weights are fixed (random init of
+the default architecture, heads made non-zero), start states synthetic.  Default workload:
+BASELINE config 2, the default config (B = 16 trajectories per GPU).  With N > 1 every rank runs
+its own B trajectories (trajectories are independent: no collective on the data path) and the
+reported value is the whole-job rate (weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec
+MFMA_F32_TFLOPS = 157.3   # dense fp32 matrix peak
+# algorithmic work per imagined latent step (default dims, A = 6), dense form:
+# actor 2,103,296 + seq.linear 1,114,112 + GRU 3,145,728 + dyn 2,621,440 + rew/cont 2 x 2,622,464
+# + critic value 2,358,272
+FLOP_PER_LATENT_STEP = 16_587_776
+
+
+def build_models(device, actions=6, seed=0):
+    from dreamer_amd.actor import Actor
+    from dreamer_amd.config import Config
+    from dreamer_amd.critic import Critic
+    from dreamer_amd.world_model import WorldModel
+    cfg = Config()
+    torch.manual_seed(seed)
+    wm = WorldModel((3, 64, 64), actions, cfg.num_latents, cfg.classes_per_latent, cfg.hidden_size,
+                    cfg.base_cnn_channels, cfg.mlp_hidden_units, cfg.free_bits, cfg.beta_pred, cfg.beta_dyn,
+                    cfg.beta_rep, cfg.unimix_eps)
+    S = cfg.hidden_size + cfg.num_latents * cfg.classes_per_latent
+    actor = Actor(S, actions, cfg.mlp_hidden_units, 2, cfg.actor_entropy_scale, cfg.actor_ret_norm_limit,
+                  cfg.actor_ret_norm_decay, cfg.unimix_eps)
+    critic = Critic(S, cfg.mlp_hidden_units, 2, cfg.critic_num_buckets, cfg.critic_bucket_min, cfg.critic_bucket_max,
+                    cfg.critic_ema_decay, cfg.critic_ema_regularizer)
+    with torch.no_grad():  # zero-initialised heads would make R = 0, C = 0.5 and a uniform policy
+        for head in (wm.rew.head, wm.cont.head, actor.head, critic.head):
+            torch.nn.init.normal_(head.weight, std=0.05)
+            torch.nn.init.normal_(head.bias, std=0.05)
+    return cfg, wm.to(device), actor.to(device), critic.to(device)
+
+
+def start_states(B, cfg, device, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    h0 = torch.tanh(torch.randn(B, cfg.hidden_size, generator=g))
+    idx = torch.randint(0, cfg.classes_per_latent, (B, cfg.num_latents), generator=g)
+    z0 = torch.nn.functional.one_hot(idx, cfg.classes_per_latent).float()
+    return h0.to(device), z0.to(device)
+
+
+def cpu_baseline(cfg, wm, actor, critic, B, H, budget_s=15.0):
+    """The oracle (CPU restatement of the reference, decoder call included as the reference makes it)
+    timed on the host cores for the same B x H block."""
+    import oracle as O
+    ww = {k: v.detach().cpu() for k, v in wm.state_dict().items()}
+    wa = {k: v.detach().cpu() for k, v in actor.state_dict().items()}
+    wc = {k: v.detach().cpu() for k, v in critic.state_dict().items()}
+    h0, z0 = start_states(B, cfg, "cpu")
+    A, L, K = wm.action_size, cfg.num_latents, cfg.classes_per_latent
+
+    def once():
+        ea = torch.empty(H, B, A).exponential_()
+        ez = torch.empty(H, B, L, K).exponential_()
+        with torch.no_grad():
+            O.imagine_block(ww, wa, wc, h0, z0, ea, ez, cfg.gamma, cfg.lam, cfg.unimix_eps, run_decoder=True)
+
+    once()
+    t0 = time.perf_counter()
+    once()
+    per = time.perf_counter() - t0
+    reps = max(3, min(200, int(budget_s / max(per, 1e-3))))
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        once()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B * H / med, "unit": "imagined latent steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} repetitions of the B={B} x H={H} imagination block (median), decoder call included as in the "
+                      f"reference; {os.cpu_count()} logical CPUs visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="imagine16", choices=["imagine16", "imagine4096"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from dreamer_amd import _native as N
+    from dreamer_amd.imagine import ImagineEngine
+    from dreamer_amd.world_model import WorldModelState
+
+    N.check(N.lib().drm_arch_ok(), "drm_arch_ok")
+    B = 16 if args.workload == "imagine16" else 4096
+    cfg, wm, actor, critic = build_models(device)
+    H = cfg.imagination_horizon
+    eng = ImagineEngine(wm, actor, critic)
+    h0, z0 = start_states(B, cfg, device, seed=1 + rank)
+    start = WorldModelState(h=h0, z=z0)
+    zidx0 = N.onehot_to_index(z0)
+    A, L, K = wm.action_size, cfg.num_latents, cfg.classes_per_latent
+
+    def step():
+        noise = {"a": torch.empty(H, B, A, device=device).exponential_(),
+                 "z": torch.empty(H, B, L, K, device=device).exponential_()}
+        return eng.run(start, H, cfg.gamma, cfg.lam, noise=noise, start_zidx=zidx0, repack=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out["lam_returns"]).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel timing with HIP events on the launch stream, in a separate short pass
+    roofline = None
+    if rank == 0 and args.profile_steps > 0:
+        N.prof_enable(True)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        summ = N.prof_summary()
+        N.prof_enable(False)
+        name, rec = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_s = rec["ms"] * 1e-3 / rec["launches"]
+        ai = rec["flops"] / max(rec["bytes"], 1.0)
+        if ai >= MFMA_F32_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+            ach = rec["flops"] / rec["launches"] / per_launch_s / 1e12
+            roofline = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_TFLOPS, "traffic": None}
+        else:
+            ach = rec["bytes"] / rec["launches"] / per_launch_s / 1e9
+            roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None}
+        roofline.update(kernel=name, launches_per_step=rec["launches"] / args.profile_steps,
+                        avg_launch_us=per_launch_s * 1e6, share_of_kernel_time=rec["ms"] / sum(r["ms"] for r in summ.values()),
+                        kernels={k: {"us_per_step": v["ms"] * 1e3 / args.profile_steps, "launches_per_step": v["launches"] / args.profile_steps}
+                                 for k, v in summ.items()})
+
+    if rank == 0:
+        value = world * B * H * args.steps / elapsed
+        line = {
+            "metric": "imagined latent steps/sec", "value": value, "unit": "imagined latent steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"imagination block, default config (D=512, 32x32 latent, mlp 512, A=6), B={B} start "
+                                   f"states per GPU x H={H}, fp32, noise generation included",
+                       "B_per_gpu": B, "H": H},
+            "algorithmic_tflops": value * FLOP_PER_LATENT_STEP / 1e12,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, wm, actor, critic, 16, H)
+            line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

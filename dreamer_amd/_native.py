@@ -73,6 +73,10 @@ SIGNATURES = {
     "drm_version": (C.c_int, []),
     "drm_last_error": (C.c_char_p, []),
     "drm_arch_ok": (C.c_int, []),
+    "drm_prof_enable": (C.c_int, [C.c_int]),
+    "drm_prof_class_name": (C.c_char_p, [C.c_int]),
+    "drm_prof_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
     "drm_lambda_return": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
     "drm_seq_gather": (C.c_int, [C.POINTER(drm_ring), C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "drm_sample_categorical_st": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
@@ -205,3 +209,21 @@ def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int =
     a.M, a.N, a.K = M, N, K
     check(lib().drm_fused_linear_f32(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_f32")
     return y
+
+
+PROF_CLASSES = 10
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().drm_prof_enable(1 if on else 0), "drm_prof_enable")
+
+
+def prof_summary():
+    """{kernel class name: dict(ms, launches, flops, bytes)} for the launches recorded since prof_enable(True)."""
+    out = {}
+    for cls in range(PROF_CLASSES):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib().drm_prof_summary(cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "drm_prof_summary")
+        if n.value:
+            out[lib().drm_prof_class_name(cls).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out

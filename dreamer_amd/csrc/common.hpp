@@ -32,6 +32,18 @@ void set_error(const std::string& msg);
 
 #define DRM_LAUNCH_CHECK() DRM_HIP(hipGetLastError())
 
+// kernel classes for the optional per-launch timing
+enum ProfClass { PC_LINEAR = 0, PC_GRU, PC_DYN_SAMPLE, PC_ACTOR_HEAD, PC_SCALAR_HEADS, PC_CRITIC_VALUE, PC_LAMBDA,
+                 PC_GATHER, PC_SAMPLE, PC_PACK };
+bool prof_on();
+void prof_begin(int cls, hipStream_t s, double flops, double bytes);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(int cls, hipStream_t st, double flops, double bytes) : s(st), on(prof_on()) { if (on) prof_begin(cls, s, flops, bytes); }
+    ~ProfScope() { if (on) prof_end(s); }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -250,6 +250,13 @@ static int launch_store(const ProblemSpec* specs, int np, int M, const uint8_t* 
         tiles += (specs[i].N + 15) / 16;
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
+    double fl = 0, by = 0;
+    for (int i = 0; i < np; ++i) {
+        const double n = specs[i].N, k = specs[i].K, m = M;
+        fl += 2.0 * m * n * k + (specs[i].tab ? (double)latents * m * n : 0.0);
+        by += 4.0 * (m * k + n * k + n + m * n) + (specs[i].tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
+    }
+    ProfScope prof(PC_LINEAR, stream, fl, by);
     k_linear16<1, EPI_STORE><<<dim3(tiles, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{});
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -262,6 +269,8 @@ static int launch_gru(const ProblemSpec& spec, int M, const GruEpilogue& G, hipS
     LinProblem& p = L.p[0];
     p.X = spec.X; p.ldx = spec.ldx; p.W = spec.W; p.ldw = spec.ldw; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
     L.np = 1; L.M = M;
+    ProfScope prof(PC_GRU, stream, 2.0 * M * spec.N * spec.K + 12.0 * M * G.D,
+                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + 5.0 * M * G.D + M * G.D));
     k_linear16<3, EPI_GRU><<<dim3(G.D / 16, (M + 15) / 16), dim3(256), 0, stream>>>(L, G, SampleEpilogue{});
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -275,6 +284,8 @@ static int launch_sample(const ProblemSpec& spec, int M, int latents, const Samp
     p.X = spec.X; p.ldx = spec.ldx; p.ln_g = spec.ln_g; p.ln_b = spec.ln_b; p.W = spec.W; p.ldw = spec.ldw;
     p.bias = spec.bias; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
     L.np = 1; L.M = M;
+    ProfScope prof(PC_DYN_SAMPLE, stream, 2.0 * M * spec.N * spec.K,
+                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + (double)M * spec.N) + (double)M * latents);
     k_linear16<2, EPI_SAMPLE><<<dim3(latents, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, S);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -373,6 +384,7 @@ extern "C" int drm_pack_imagine(const drm_imagine_weights* w, float* pack_out, s
         {w->actor.w[0], S, d.D, d.M, pl.actor_zT}, {w->critic.w[0], S, d.D, d.M, pl.critic_zT},
         {w->rew.w[0], S, d.D, d.M, pl.rew_zT},     {w->cont.w[0], S, d.D, d.M, pl.cont_zT},
         {w->lin_w, LK + d.E, 0, d.D, pl.lin_zT}};
+    ProfScope prof(PC_PACK, s, 2.0 * d.A * d.D * d.E, 8.0 * ((double)LK * (4.0 * d.M + d.D)) + 4.0 * d.A * d.D);
     for (auto& j : jobs) {
         k_transpose_cols<<<dim3((LK + 31) / 32, (j.nrows + 31) / 32), dim3(256), 0, s>>>(j.W, j.ldw, j.col0, LK, j.nrows,
                                                                                          pack_out + j.off);
@@ -454,6 +466,8 @@ extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_ima
             a.a_used = io->actions_out + t; a.ldau = H;
             a.a_sampled = io->actions_sampled_out ? io->actions_sampled_out + t : nullptr; a.ldas = H;
             a.logp_out = io->actor_logp_out ? io->actor_logp_out + (size_t)t * d.A : nullptr; a.ldlp = (int64_t)H * d.A;
+            ProfScope prof(PC_ACTOR_HEAD, s, 2.0 * B * M * d.A + (double)B * D * (L + 1),
+                           4.0 * ((double)B * M + (double)d.A * M + (double)B * D * (L + 2)));
             k_actor_head_x<<<dim3(B), dim3(256), (size_t)M * sizeof(float), s>>>(a);
             DRM_LAUNCH_CHECK();
         }
@@ -527,12 +541,16 @@ extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_ima
             a.h[i] = ScalarHead{ws + wl.head[i][last & 1], M, m.ln_g[last], m.ln_b[last], m.head_w, m.head_b,
                                 i == 0 ? io->rewards_out : io->conts_out, nullptr, i == 0 ? 1 : 2};
         }
+        ProfScope prof(PC_SCALAR_HEADS, s, 4.0 * rows * M, 4.0 * (2.0 * rows * M + 6.0 * M + 2.0 * rows));
         k_scalar_heads<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(a);
         DRM_LAUNCH_CHECK();
     }
-    k_critic_value<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(ws + wl.critic_logits, 256, d.NB, w->buckets, rows, H,
-                                                              io->values_out, io->v_last_out);
-    DRM_LAUNCH_CHECK();
+    {
+        ProfScope prof(PC_CRITIC_VALUE, s, 4.0 * rows * d.NB, 4.0 * ((double)rows * d.NB + d.NB + rows));
+        k_critic_value<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(ws + wl.critic_logits, 256, d.NB, w->buckets, rows, H,
+                                                                  io->values_out, io->v_last_out);
+        DRM_LAUNCH_CHECK();
+    }
     return drm_lambda_return(io->rewards_out, io->conts_out, io->values_out, io->v_last_out, io->lam_returns_out, B, H,
                              io->gamma, io->lam, stream);
 }

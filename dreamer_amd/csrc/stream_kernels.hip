@@ -51,6 +51,23 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
     }
 }
 
+// Long horizons (rows no longer fit LDS): one lane per trajectory straight from global memory.
+__global__ __launch_bounds__(64) void k_lambda_return_long(const float* __restrict__ R, const float* __restrict__ C,
+                                                           const float* __restrict__ V, const float* __restrict__ VL,
+                                                           float* __restrict__ out, int64_t B, int H, float gamma,
+                                                           float one_minus_lam, float lam) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float nxt = VL[b];
+    for (int t = H - 1; t >= 0; --t) {
+        const int64_t i = b * H + t;
+        const float disc = __fmul_rn(gamma, __fsub_rn(1.0f, C[i]));
+        const float mix = __fadd_rn(__fmul_rn(one_minus_lam, V[i]), __fmul_rn(lam, nxt));
+        nxt = __fadd_rn(R[i], __fmul_rn(disc, mix));
+        out[i] = nxt;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // replay sequence gather.  One block per (b, t) frame: 16-byte lane accesses, consecutive lanes on
 // consecutive 16-byte chunks (1 KiB per wave instruction).  Lane 0 moves the three scalars.
@@ -164,14 +181,15 @@ extern "C" int drm_lambda_return(const float* R, const float* C, const float* V,
     const int HP = H | 1;
     const float g = (float)gamma, oml = (float)(1.0 - lam), l = (float)lam;
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PC_LAMBDA, s, 6.0 * B * H, 16.0 * B * H + 4.0 * B);
     if ((size_t)3 * 256 * HP * 4 <= 64 * 1024) {
         const size_t sh = (size_t)3 * 256 * HP * 4;
         k_lambda_return<256><<<dim3((unsigned)((B + 255) / 256)), dim3(256), sh, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
-    } else {
+    } else if ((size_t)3 * 64 * HP * 4 <= 64 * 1024) {
         const size_t sh = (size_t)3 * 64 * HP * 4;
-        DRM_REQUIRE(sh <= 160 * 1024, DRM_ENOTSUP, "horizon %d too long for the LDS scan", H);
-        DRM_HIP(hipFuncSetAttribute((const void*)k_lambda_return<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         k_lambda_return<64><<<dim3((unsigned)((B + 63) / 64)), dim3(64), sh, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
+    } else {
+        k_lambda_return_long<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
     }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -189,6 +207,9 @@ extern "C" int drm_seq_gather(const drm_ring* ring, const int64_t* starts, int32
     DRM_REQUIRE(aligned16(ring->observations) && aligned16(obs_out) && aligned16(obs_f32_out), DRM_EINVAL,
                 "observation pointers must be 16-byte aligned");
     if (B == 0) return DRM_OK;
+    const double units = (double)B * T;
+    ProfScope prof(PC_GATHER, (hipStream_t)stream, 0.0,
+                   units * (2.0 * (ring->frame_bytes + 8 + 4 + 1) + (obs_f32_out ? 4.0 * ring->frame_bytes : 0.0)));
     k_seq_gather<<<dim3((unsigned)((int64_t)B * T)), dim3(256), 0, (hipStream_t)stream>>>(
         *ring, starts, T, obs_out, actions_out, rewards_out, continues_out, obs_f32_out);
     DRM_LAUNCH_CHECK();
@@ -209,6 +230,8 @@ extern "C" int drm_sample_categorical_st(const float* logits, const float* expo,
     const float lek = use ? (float)(log((double)unimix_eps) - log(32.0)) : 0.f;
     const int64_t blocks = (rows + 31) / 32;
     const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    ProfScope prof(PC_SAMPLE, (hipStream_t)stream, 40.0 * rows * 32,
+                   (double)rows * (256.0 + (z_out ? 128.0 : 0.0) + (y_out ? 128.0 : 0.0) + (idx_out ? 1.0 : 0.0)));
     k_sample_st<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(logits, expo, rows, l1m, lek, use, z_out, idx_out, y_out);
     DRM_LAUNCH_CHECK();
     return DRM_OK;

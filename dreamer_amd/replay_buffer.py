@@ -38,6 +38,11 @@ class ReplayBuffer:
     def store_many(self, obs, actions, rewards, conts) -> None:
         """Append n transitions at once (same final state as n ``store`` calls)."""
         n = len(actions)
+        if n > self.capacity:  # only the last `capacity` transitions survive; keep ring positions distinct
+            skip = n - self.capacity
+            self.idx, self.full = (self.idx + skip) % self.capacity, True
+            obs, actions, rewards, conts = obs[skip:], actions[skip:], rewards[skip:], conts[skip:]
+            n = self.capacity
         pos = (self.idx + np.arange(n)) % self.capacity
         pos_t = torch.as_tensor(pos, device=self.device)
         self.observations[pos_t] = torch.as_tensor(obs, dtype=torch.uint8).to(self.device)

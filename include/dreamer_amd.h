@@ -47,6 +47,16 @@ const char* drm_last_error(void);
 /* 0 if the current HIP device is gfx950, DRM_EARCH otherwise. */
 int drm_arch_ok(void);
 
+/* ---- per-kernel timing (measurement only; no counterpart in the reference) -------------------
+ * While enabled, every kernel launch made by this library is bracketed by two HIP events on
+ * the stream it is launched on, and its algorithmic work (flops; bytes with every operand read
+ * once and every result written once) is recorded under its kernel class.  drm_prof_enable(1)
+ * clears earlier records; drm_prof_summary() waits for the recorded events. */
+#define DRM_PROF_CLASSES 10
+int drm_prof_enable(int enable);
+const char* drm_prof_class_name(int cls);
+int drm_prof_summary(int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
 /* ---- lambda-return scan: lib/trainer.py:217-224 --------------------------------------------
  * ret[b,t] = R[b,t] + gamma*(1 - C[b,t])*((1-lam)*V[b,t] + lam*ret[b,t+1]),  ret[b,H] = V_last[b].
  * R, C, V, out: (B,H) with t contiguous; V_last: (B).  gamma and lam are the Python floats of

@@ -1,0 +1,101 @@
+"""The native imagination block against the reference's golden vectors and the oracle (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from dreamer_amd.imagine import ImagineEngine
+from dreamer_amd.testing import hash_exponential
+from dreamer_amd.world_model import WorldModelState
+from helpers import DIMS, build_models, expo, load, rel_err, start_state, weights_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5   # north-star tolerance for fp32 rollout states, lambda-returns and losses
+
+
+def _engine(d, salt, **kw):
+    wm, actor, critic = build_models(d, salt, **kw)
+    return wm, actor, critic, ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+
+
+@pytest.mark.parametrize("tag", ["small", "default"])
+def test_free_running_rollout_matches_reference(tag):
+    g = load(f"imagine_{tag}.npz")
+    d, salt = DIMS[tag], int(g["salt"])
+    wm, actor, critic, eng = _engine(d, salt)
+    h0, z0, _ = start_state(d, salt)
+    noise = {"a": torch.from_numpy(g["noise_a"]).to(DEV), "z": expo("imagine_z", (d["H"], d["B"], d["L"], d["K"]), salt).to(DEV)}
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), d["H"], float(g["gamma"]), float(g["lam"]), noise=noise,
+                  want_prior_logits=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["actions"].cpu().numpy(), g["actions"])
+    assert np.array_equal(out["zidx"].cpu().numpy(), g["zidx"])
+    assert torch.equal(out["z"].cpu().argmax(-1).to(torch.uint8), out["zidx"].cpu())
+    assert float(out["z"].sum()) == d["B"] * d["H"] * d["L"]
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp"):
+        assert rel_err(out[key].cpu(), g[key]) < TOL, key
+    if tag == "small":
+        assert rel_err(out["prior_logits"].cpu(), g["prior_logits"].reshape(out["prior_logits"].shape)) < TOL
+    # losses computed from the native outputs (lib/trainer.py:227-247) within the same tolerance
+    Hs = WorldModelState(h=out["h"], z=out["z"])
+    cl = critic.loss(Hs, out["lam_returns"])
+    al = actor.loss(Hs, out["actions"], out["lam_returns"], out["values"])
+    assert rel_err(cl.detach().cpu(), g["critic_loss"]) < TOL and rel_err(al.detach().cpu(), g["actor_loss"]) < TOL
+
+
+@pytest.mark.parametrize("layers", [(1, 1), (3, 3), (2, 4)])
+@pytest.mark.parametrize("B,H", [(1, 1), (5, 3), (16, 15), (37, 4)])
+def test_teacher_forced_vs_oracle(B, H, layers):
+    d = dict(DIMS["small"], D=96, M=128, L=6, A=7)
+    salt = 100 + B + H
+    wm, actor, critic = build_models(d, salt, actor_layers=layers[0], critic_layers=layers[1])
+    ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    with torch.no_grad():
+        ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
+    ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea.to(DEV), "z": ez.to(DEV)},
+                  forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV), want_prior_logits=True,
+                  want_sampled=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out["zidx"].cpu(), ref_zidx) and torch.equal(out["actions"].cpu(), ref["actions"])
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+        assert rel_err(out[key].cpu(), ref[key]) < TOL, key
+    # what the sampler drew must agree with the oracle wherever the draw is not a near-tie
+    lp = O.log_unimix(ref["prior_logits"], 0.01) - ez.permute(1, 0, 2, 3).log()
+    top2 = lp.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert torch.equal(out["zidx_sampled"].cpu()[clear], ref_zidx[clear])
+    sc = (ref["actor_logp"].softmax(-1) / ea.permute(1, 0, 2)).log()
+    t2 = sc.topk(2, dim=-1).values
+    clear_a = (t2[..., 0] - t2[..., 1]) > 1e-4
+    assert torch.equal(out["actions_sampled"].cpu()[clear_a], ref["actions"][clear_a])
+
+
+def test_large_batch_properties():
+    """B = 4096 trajectories (BASELINE config 3): rows are independent, so any slice of the batch
+    must reproduce, bit for bit, what the same rows give when run alone."""
+    d, salt, B, H = DIMS["default"], 5, 4096, 15
+    wm, actor, critic, eng = _engine(d, salt)
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt)).to(DEV)
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt)).to(DEV)
+    full = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False)
+    rows = slice(1000, 1016)
+    part = eng.run(WorldModelState(h=h0[rows].to(DEV), z=z0[rows].to(DEV)), H, 0.997, 0.95,
+                   noise={"a": ea[:, rows].contiguous(), "z": ez[:, rows].contiguous()}, want_dense_z=False)
+    torch.cuda.synchronize()
+    for key in ("h", "zidx", "actions", "rewards", "conts", "values", "lam_returns"):
+        assert torch.equal(full[key][rows].cpu(), part[key].cpu()), key
+    assert torch.isfinite(full["lam_returns"]).all()
+    # the 16 rows against the oracle, free running
+    with torch.no_grad():
+        ref = O.imagine_block(weights_of(wm), weights_of(actor), weights_of(critic), h0[rows], z0[rows],
+                              ea[:, rows].cpu(), ez[:, rows].cpu(), 0.997, 0.95)
+    same = torch.equal(part["zidx"].cpu(), ref["z"].argmax(-1).to(torch.uint8)) and torch.equal(part["actions"].cpu(), ref["actions"])
+    if same:   # no near-tie among these draws: states must agree to tolerance
+        assert rel_err(part["h"].cpu(), ref["h"]) < TOL and rel_err(part["lam_returns"].cpu(), ref["lam_returns"]) < TOL

@@ -1,0 +1,60 @@
+"""The fused linear block (fp32 MFMA) against plain fp32 PyTorch on the host (GPU)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dreamer_amd import _native as N
+from dreamer_amd.testing import hash_uniform
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(name, shape, scale=1.0, salt=0):
+    return torch.from_numpy(((hash_uniform(name, shape, salt) * 2 - 1) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("M,N_,K", [(16, 512, 512), (16, 1536, 512), (1, 6, 512), (5, 255, 64), (240, 512, 512),
+                                    (37, 70, 96), (16, 1024, 512), (4, 64, 64), (1000, 96, 128)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_linear_vs_torch(M, N_, K, ln):
+    x = _t("x", (M, K), 2.0, M)
+    w = _t("w", (N_, K), 1.0 / np.sqrt(K), N_)
+    b = _t("b", (N_,), 0.1)
+    g, be = 1.0 + _t("g", (K,), 0.2), _t("be", (K,), 0.1)
+    a = F.silu(F.layer_norm(x, (K,), g, be, 1e-5)) if ln else x
+    ref = (a.double() @ w.double().T + b.double()).float()
+    y = N.fused_linear(x.to(DEV), w.to(DEV), b.to(DEV), ln=(g.to(DEV), be.to(DEV)) if ln else None)
+    scale = float(ref.abs().max())
+    assert float((y.cpu() - ref).abs().max()) < 2e-6 * max(scale, 1.0) * np.sqrt(K / 64)
+
+
+def test_asymmetric_identity_layout():
+    # X = I picks out columns of W: catches any row/column swap in the fragment maps
+    K = 64
+    x = torch.eye(K)[:16]
+    w = torch.arange(48 * K, dtype=torch.float32).reshape(48, K)
+    y = N.fused_linear(x.to(DEV), w.to(DEV))
+    assert torch.equal(y.cpu(), w[:, :16].T.contiguous())
+
+
+def test_linear_with_onehot_table_and_strided_weight():
+    M, D, L, K, Nn = 23, 128, 8, 32, 96
+    x = _t("x", (M, D))
+    w_full = _t("w", (Nn, D + L * K), 0.05)          # Linear over cat[h, z_flat]
+    b = _t("b", (Nn,), 0.1)
+    idx = torch.from_numpy((hash_uniform("i", (M, L), 5) * K).astype(np.int64))
+    z = F.one_hot(idx, K).float().reshape(M, L * K)
+    ref = (torch.cat([x, z], -1).double() @ w_full.double().T + b.double()).float()
+    table = w_full[:, D:].T.contiguous()
+    wd = w_full.to(DEV)
+    y = N.fused_linear(x.to(DEV), wd[:, :D], b.to(DEV), table=table.to(DEV), zidx=idx.to(torch.uint8).to(DEV))
+    assert float((y.cpu() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+
+
+def test_linear_rejects_bad_shapes():
+    x = torch.zeros(4, 48, device=DEV)
+    w = torch.zeros(8, 48, device=DEV)
+    with pytest.raises(N.NativeError):
+        N.fused_linear(x, w)   # K not a multiple of 32
