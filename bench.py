@@ -130,9 +130,8 @@ def main():
     A, L, K = wm.action_size, cfg.num_latents, cfg.classes_per_latent
 
     def step():
-        noise = {"a": torch.empty(H, B, A, device=device).exponential_(),
-                 "z": torch.empty(H, B, L, K, device=device).exponential_()}
-        return eng.run(start, H, cfg.gamma, cfg.lam, noise=noise, start_zidx=zidx0, repack=False)
+        # draws the Exp(1) noise of the block (two generator calls) and runs the block
+        return eng.run(start, H, cfg.gamma, cfg.lam, start_zidx=zidx0, repack=False, persistent=True)
 
     def fence():
         torch.cuda.synchronize()

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdreamer_amd.so")
+LIB_PATH = os.environ.get("DRM_LIB", os.path.join(_HERE, "libdreamer_amd.so"))
 _lib = None
 
 DRM_MAX_MLP_LAYERS = 4
@@ -65,7 +65,7 @@ class drm_imagine_io(C.Structure):
                 ("prior_logits_out", C.c_void_p), ("rewards_out", C.c_void_p), ("conts_out", C.c_void_p),
                 ("values_out", C.c_void_p), ("v_last_out", C.c_void_p), ("lam_returns_out", C.c_void_p),
                 ("gamma", C.c_double), ("lam", C.c_double), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("use_graph", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/dreamer_amd.h declares
@@ -87,6 +87,7 @@ SIGNATURES = {
     "drm_pack_imagine": (C.c_int, [C.POINTER(drm_imagine_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
     "drm_imagine_block_f32": (C.c_int, [C.POINTER(drm_imagine_weights), C.POINTER(drm_imagine_io), C.c_void_p]),
+    "drm_graph_cache_clear": (C.c_int, []),
 }
 
 

@@ -74,3 +74,4 @@ extern "C" int drm_arch_ok(void) {
                 dev, prop.gcnArchName);
     return DRM_OK;
 }
+

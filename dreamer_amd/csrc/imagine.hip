@@ -4,6 +4,10 @@
 // boundary; inside a kernel the output columns are spread over the CUs.
 #include "linear16.hpp"
 
+#include <cstring>
+#include <mutex>
+#include <vector>
+
 namespace drm {
 
 // ------------------------------------------------------------------------------------------------
@@ -73,36 +77,66 @@ struct ActorHeadArgs {
     float* logp_out; int64_t ldlp;           // nullable
 };
 
+// M <= 512 and D <= 512: every thread owns at most two features / two output columns, and every
+// global load that does not depend on the drawn action is issued at the top of the kernel (the
+// one-hot table rows of x only need z, so they are in flight while the policy is evaluated; the
+// action-table rows of all actions are prefetched and selected afterwards).
+template <int AMAX, int LMAX>
 __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
-    extern __shared__ __attribute__((aligned(16))) float s_act[];   // M floats
     __shared__ float s4[4];
-    __shared__ float s_logit[64];
+    __shared__ uint8_t s_z[LMAX];
+    __shared__ float s_dot[4][AMAX];
     __shared__ int s_a;
-    __shared__ uint8_t s_z[256];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const float* pre = P.pre + (int64_t)b * P.ldp;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < P.M; i += 256) { const float v = pre[i]; s_act[i] = v; s += v; }
-    const float mean = block_sum_256(s, s4) / (float)P.M;
-    float qv = 0.f;
-    for (int i = threadIdx.x; i < P.M; i += 256) { const float d = s_act[i] - mean; qv += d * d; }
-    const float rstd = 1.0f / sqrtf(block_sum_256(qv, s4) / (float)P.M + LN_EPS);
-    for (int i = threadIdx.x; i < P.M; i += 256) s_act[i] = silu_f((s_act[i] - mean) * rstd * P.ln_g[i] + P.ln_b[i]);
-    for (int l = threadIdx.x; l < P.latents; l += 256) s_z[l] = P.zidx[(int64_t)b * P.ldz + l];
+    const int i0 = tid, i1 = tid + 256;
+    const bool on0 = i0 < P.M, on1 = i1 < P.M;
+    const bool jn0 = i0 < P.D, jn1 = i1 < P.D;
+    // ---- loads, level 1
+    if (tid < P.latents) s_z[tid] = P.zidx[(int64_t)b * P.ldz + tid];
+    const float x0 = on0 ? pre[i0] : 0.f, x1 = on1 ? pre[i1] : 0.f;
+    const float g0 = on0 ? P.ln_g[i0] : 0.f, g1 = on1 ? P.ln_g[i1] : 0.f;
+    const float e0 = on0 ? P.ln_b[i0] : 0.f, e1 = on1 ? P.ln_b[i1] : 0.f;
+    float hw0[AMAX], hw1[AMAX], at0[AMAX], at1[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        const bool aa = a < P.A;
+        hw0[a] = (aa && on0) ? P.head_w[(int64_t)a * P.M + i0] : 0.f;
+        hw1[a] = (aa && on1) ? P.head_w[(int64_t)a * P.M + i1] : 0.f;
+        at0[a] = (aa && jn0) ? P.a_tab[(int64_t)a * P.D + i0] : 0.f;
+        at1[a] = (aa && jn1) ? P.a_tab[(int64_t)a * P.D + i1] : 0.f;
+    }
+    const float ex = lane < P.A ? P.expo[(int64_t)b * P.lde + lane] : 1.f;
+    const float hb = lane < P.A ? P.head_b[lane] : 0.f;
+    float xz0 = jn0 ? P.lin_b[i0] : 0.f, xz1 = jn1 ? P.lin_b[i1] : 0.f;
+    // ---- loads, level 2: table rows selected by z, all in flight together
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int a = wave; a < P.A; a += 4) {
-        const float* w = P.head_w + (int64_t)a * P.M;
-        float d = 0.f;
-        for (int i = lane; i < P.M; i += 64) d = fmaf(s_act[i], w[i], d);
-        d = group_sum<64>(d);
-        if (lane == 0) s_logit[a] = d + P.head_b[a];
+    float u0[LMAX], u1[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        const bool ok = l < P.latents;
+        const int64_t rowoff = ok ? (int64_t)(l * P.classes + s_z[l]) * P.D : 0;
+        u0[l] = (ok && jn0) ? P.lin_zT[rowoff + i0] : 0.f;
+        u1[l] = (ok && jn1) ? P.lin_zT[rowoff + i1] : 0.f;
+    }
+    // ---- LayerNorm + SiLU
+    const float mean = block_sum_256(x0 + x1, s4) / (float)P.M;
+    const float d0 = on0 ? x0 - mean : 0.f, d1 = on1 ? x1 - mean : 0.f;
+    const float rstd = 1.0f / sqrtf(block_sum_256(d0 * d0 + d1 * d1, s4) / (float)P.M + LN_EPS);
+    const float a0 = on0 ? silu_f(d0 * rstd * g0 + e0) : 0.f, a1 = on1 ? silu_f(d1 * rstd * g1 + e1) : 0.f;
+    // ---- head: per-thread partial dots, wave reduce, cross-wave through LDS
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        const float d = group_sum<64>(fmaf(a0, hw0[a], a1 * hw1[a]));
+        if (lane == 0) s_dot[wave][a] = d;
     }
     __syncthreads();
     if (wave == 0) {
         const bool on = lane < P.A;
         const float NEG = -3.0e38f;
-        const float lg = on ? s_logit[lane] : NEG;
+        const int la = on ? lane : 0;
+        const float lg = on ? ((s_dot[0][la % AMAX] + s_dot[1][la % AMAX]) + (s_dot[2][la % AMAX] + s_dot[3][la % AMAX])) + hb : NEG;
         const float mx = group_max<64>(lg);
         const float lse = logf(group_sum<64>(on ? expf(lg - mx) : 0.f));
         const float mixed = on ? logaddexp_f((lg - mx - lse) + P.log1m_eps, P.log_eps_over_a) : NEG;
@@ -112,9 +146,9 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
         const float logp = mixed - lse2;
         // probs = softmax(logp); multinomial draws argmax(probs / E)
         const float mx3 = group_max<64>(on ? logp : NEG);
-        const float ex = on ? expf(logp - mx3) : 0.f;
-        const float prob = ex / group_sum<64>(ex);
-        float score = on ? prob / P.expo[(int64_t)b * P.lde + lane] : -1.f;
+        const float pe = on ? expf(logp - mx3) : 0.f;
+        const float prob = pe / group_sum<64>(pe);
+        float score = on ? prob / ex : -1.f;
         int ai = lane;
         group_argmax<64>(score, ai);
         if (on && P.logp_out) P.logp_out[(int64_t)b * P.ldlp + lane] = logp;
@@ -127,13 +161,16 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
         }
     }
     __syncthreads();
-    const int a = s_a;
-    for (int j = threadIdx.x; j < P.D; j += 256) {
-        float acc = P.lin_b[j];
-        for (int l = 0; l < P.latents; ++l) acc += P.lin_zT[(int64_t)(l * P.classes + s_z[l]) * P.D + j];
-        acc += P.a_tab[(int64_t)a * P.D + j];
-        P.x[(int64_t)b * P.ldxo + j] = acc;
+    const int act = s_a;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) { xz0 += u0[l]; xz1 += u1[l]; }
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        if (a == act) { t0 = at0[a]; t1 = at1[a]; }
     }
+    if (jn0) P.x[(int64_t)b * P.ldxo + i0] = xz0 + t0;
+    if (jn1) P.x[(int64_t)b * P.ldxo + i1] = xz1 + t1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -227,7 +264,7 @@ struct ProblemSpec {
 
 static int check_problem(const ProblemSpec& s) {
     DRM_REQUIRE(s.X && s.W && s.Y, DRM_EINVAL, "null pointer in linear problem");
-    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0, DRM_ENOTSUP, "K=%d must be a positive multiple of 32", s.K);
+    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0 && s.K <= 512, DRM_ENOTSUP, "K=%d must be a multiple of 32 in [32, 512]", s.K);
     DRM_REQUIRE(s.N >= 1, DRM_EINVAL, "N=%d", s.N);
     DRM_REQUIRE(aligned16(s.X) && aligned16(s.W) && s.ldx % 4 == 0 && s.ldw % 4 == 0, DRM_EINVAL,
                 "X/W must be 16-byte aligned with row strides a multiple of 4 floats");
@@ -256,8 +293,16 @@ static int launch_store(const ProblemSpec* specs, int np, int M, const uint8_t* 
         fl += 2.0 * m * n * k + (specs[i].tab ? (double)latents * m * n : 0.0);
         by += 4.0 * (m * k + n * k + n + m * n) + (specs[i].tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
     }
+    DRM_REQUIRE(latents <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", latents, MAX_LATENTS);
+    int kmax = 0;
+    for (int i = 0; i < np; ++i) kmax = specs[i].K > kmax ? specs[i].K : kmax;
     ProfScope prof(PC_LINEAR, stream, fl, by);
-    k_linear16<1, EPI_STORE><<<dim3(tiles, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{});
+    const dim3 grid(tiles, (M + 15) / 16), block(256);
+    switch (chunks_for(kmax)) {
+        case 1: k_linear16<1, EPI_STORE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+        case 2: k_linear16<1, EPI_STORE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+        default: k_linear16<1, EPI_STORE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+    }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -271,7 +316,12 @@ static int launch_gru(const ProblemSpec& spec, int M, const GruEpilogue& G, hipS
     L.np = 1; L.M = M;
     ProfScope prof(PC_GRU, stream, 2.0 * M * spec.N * spec.K + 12.0 * M * G.D,
                    4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + 5.0 * M * G.D + M * G.D));
-    k_linear16<3, EPI_GRU><<<dim3(G.D / 16, (M + 15) / 16), dim3(256), 0, stream>>>(L, G, SampleEpilogue{});
+    const dim3 grid(G.D / 16, (M + 15) / 16), block(256);
+    switch (chunks_for(spec.K)) {
+        case 1: k_linear16<3, EPI_GRU, 1><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+        case 2: k_linear16<3, EPI_GRU, 2><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+        default: k_linear16<3, EPI_GRU, 4><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+    }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -286,20 +336,24 @@ static int launch_sample(const ProblemSpec& spec, int M, int latents, const Samp
     L.np = 1; L.M = M;
     ProfScope prof(PC_DYN_SAMPLE, stream, 2.0 * M * spec.N * spec.K,
                    4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + (double)M * spec.N) + (double)M * latents);
-    k_linear16<2, EPI_SAMPLE><<<dim3(latents, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, S);
+    const dim3 grid(latents, (M + 15) / 16), block(256);
+    switch (chunks_for(spec.K)) {
+        case 1: k_linear16<2, EPI_SAMPLE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+        case 2: k_linear16<2, EPI_SAMPLE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+        default: k_linear16<2, EPI_SAMPLE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+    }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
 
 static int check_dims(const drm_dims& d) {
     DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
-    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0, DRM_ENOTSUP,
-                "D=%d and M=%d must be multiples of 32", d.D, d.M);
-    DRM_REQUIRE(d.L >= 1 && d.L <= 256, DRM_ENOTSUP, "latents=%d", d.L);
-    DRM_REQUIRE(d.A >= 1 && d.A <= 64, DRM_ENOTSUP, "actions=%d (max 64)", d.A);
+    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0 && d.D <= 512 && d.M <= 512, DRM_ENOTSUP,
+                "D=%d and M=%d must be multiples of 32, at most 512", d.D, d.M);
+    DRM_REQUIRE(d.L >= 1 && d.L <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", d.L, MAX_LATENTS);
+    DRM_REQUIRE(d.A >= 1 && d.A <= 32, DRM_ENOTSUP, "actions=%d (max 32)", d.A);
     DRM_REQUIRE(d.NB >= 1 && d.NB <= 256, DRM_ENOTSUP, "buckets=%d (max 256)", d.NB);
     DRM_REQUIRE(d.E >= 1, DRM_EINVAL, "E=%d", d.E);
-    DRM_REQUIRE(d.M <= 8192, DRM_ENOTSUP, "M=%d (max 8192)", d.M);
     return DRM_OK;
 }
 
@@ -409,8 +463,7 @@ extern "C" int drm_fused_linear_f32(const drm_linear_args* a, drm_stream_t strea
     return launch_store(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream);
 }
 
-extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
-    DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
+static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
     if (int rc = check_weights(*w)) return rc;
     const drm_dims& d = w->dims;
     const int B = io->B, H = io->H, D = d.D, M = d.M, L = d.L, LK = d.L * d.K, S = D + LK;
@@ -468,7 +521,9 @@ extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_ima
             a.logp_out = io->actor_logp_out ? io->actor_logp_out + (size_t)t * d.A : nullptr; a.ldlp = (int64_t)H * d.A;
             ProfScope prof(PC_ACTOR_HEAD, s, 2.0 * B * M * d.A + (double)B * D * (L + 1),
                            4.0 * ((double)B * M + (double)d.A * M + (double)B * D * (L + 2)));
-            k_actor_head_x<<<dim3(B), dim3(256), (size_t)M * sizeof(float), s>>>(a);
+            if (d.A <= 8 && L <= 32) k_actor_head_x<8, 32><<<dim3(B), dim3(256), 0, s>>>(a);
+            else if (L <= 32) k_actor_head_x<32, 32><<<dim3(B), dim3(256), 0, s>>>(a);
+            else k_actor_head_x<32, 64><<<dim3(B), dim3(256), 0, s>>>(a);
             DRM_LAUNCH_CHECK();
         }
         // GRU: gi = W_ih x, gates with the precomputed gh -> h_{t+1} written into h_out[:, t]
@@ -554,3 +609,62 @@ extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_ima
     return drm_lambda_return(io->rewards_out, io->conts_out, io->values_out, io->v_last_out, io->lam_returns_out, B, H,
                              io->gamma, io->lam, stream);
 }
+
+// ---- optional replay of the whole block as one hipGraph -----------------------------------------
+namespace drm {
+struct GraphEntry { std::vector<uint8_t> key; hipGraphExec_t exec; };
+static std::mutex g_graph_mu;
+static std::vector<GraphEntry> g_graphs;
+constexpr size_t MAX_GRAPHS = 16;
+}  // namespace drm
+
+extern "C" int drm_graph_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& e : g_graphs) (void)hipGraphExecDestroy(e.exec);
+    g_graphs.clear();
+    return DRM_OK;
+}
+
+extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
+    DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
+    if (!io->use_graph || prof_on()) return imagine_enqueue(w, io, stream);
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    DRM_HIP(hipGetDevice(&dev));
+    std::vector<uint8_t> key(sizeof(*w) + sizeof(*io) + sizeof(int));
+    memcpy(key.data(), w, sizeof(*w));
+    memcpy(key.data() + sizeof(*w), io, sizeof(*io));
+    memcpy(key.data() + sizeof(*w) + sizeof(*io), &dev, sizeof(int));
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& e : g_graphs)
+        if (e.key == key) { DRM_HIP(hipGraphLaunch(e.exec, s)); return DRM_OK; }
+    // first call with these pointers and shapes: record the launches on a stream of the library's
+    // own (the caller's may be the default stream, which cannot be captured), then replay
+    static thread_local hipStream_t cap = nullptr;
+    static thread_local int cap_dev = -1;
+    if (cap == nullptr || cap_dev != dev) {
+        DRM_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        cap_dev = dev;
+    }
+    DRM_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    const int rc = imagine_enqueue(w, io, (drm_stream_t)cap);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(cap, &graph);
+    if (rc != DRM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    DRM_HIP(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    DRM_HIP(ie);
+    if (g_graphs.size() >= MAX_GRAPHS) { (void)hipGraphExecDestroy(g_graphs.front().exec); g_graphs.erase(g_graphs.begin()); }
+    g_graphs.push_back(GraphEntry{std::move(key), exec});
+    DRM_HIP(hipGraphLaunch(exec, s));
+    return DRM_OK;
+}
+
+#ifdef DRM_STAMPS
+extern "C" int drm_debug_set_stamp_buffer(void* p) {
+    DRM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(drm::g_stamp_buf), &p, sizeof(p)));
+    return DRM_OK;
+}
+#endif

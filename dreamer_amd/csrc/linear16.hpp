@@ -11,8 +11,13 @@
 // products are summed over k = kc + 8q + s for q = 0..3, the same permutation for A and B.  The
 // four waves' partial tiles are added in a fixed order through LDS, so results are reproducible.
 //
-// Optional prologue: the LayerNorm + SiLU of the producing layer, applied to the A fragment as
-// it is loaded (row statistics are computed once per workgroup with a two-pass mean / variance).
+// The kernel is latency-bound, so every global load of a wave (all of its A / B fragments, the
+// LayerNorm parameters, the one-hot indices) is issued before the first use of any of them:
+// CH = chunks per wave is a template parameter and the fragments live in registers.
+//
+// Optional prologue: the LayerNorm + SiLU of the producing layer, applied to the A fragments in
+// registers; row statistics come from the fragments themselves (two-pass mean / variance, partial
+// sums combined across the four waves through LDS), so the input is read exactly once.
 // Epilogues: store (+ bias, + one-hot row gather), GRU gate combine, and categorical sampling.
 #pragma once
 #include "common.hpp"
@@ -20,6 +25,7 @@
 namespace drm {
 
 constexpr int MAX_PROBLEMS = 4;
+constexpr int MAX_LATENTS = 64;   // one-hot indices staged in LDS per row
 
 // One GEMM of a launch: Y[M,N] = f(X)[M,K] W[N,K]^T (+ bias, + one-hot table rows)
 struct LinProblem {
@@ -67,44 +73,28 @@ __device__ __forceinline__ const LinProblem& pick_problem(const LinLaunch& L, in
     return L.p[i];
 }
 
-// Row statistics of the 16 rows of this m-tile over K columns: 16 lanes per row, two passes.
-__device__ __forceinline__ void tile_row_stats(const float* X, int64_t ldx, int m0, int M, int K, float* s_mean,
-                                               float* s_rstd) {
-    const int row = threadIdx.x >> 4, c = threadIdx.x & 15;
-    const int m = min(m0 + row, M - 1);
-    const float* x = X + (int64_t)m * ldx;
-    float s = 0.f;
-    for (int k = c * 4; k < K; k += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(x + k);
-        s += (v.x + v.y) + (v.z + v.w);
-    }
-    const float mean = group_sum<16>(s) / (float)K;
-    float q = 0.f;
-    for (int k = c * 4; k < K; k += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(x + k);
-        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
-        q += (a * a + b * b) + (cc * cc + d * d);
-    }
-    const float var = group_sum<16>(q) / (float)K;
-    if (c == 0) {
-        s_mean[row] = mean;
-        s_rstd[row] = 1.0f / sqrtf(var + LN_EPS);
-    }
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-template <int NT, int EPI>
+template <int NT, int EPI, int CH>
 __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEpilogue G, const SampleEpilogue S) {
     __shared__ __attribute__((aligned(16))) float s_part[4][NT][16][16];
-    __shared__ float s_mean[16], s_rstd[16];
+    __shared__ float s_red[2][4][16];
+    __shared__ uint8_t s_zi[16][MAX_LATENTS];
 
+    STAMP_DECL
+    STAMP();
     int tile;
     const LinProblem& P = pick_problem(L, blockIdx.x, tile);
     const int m0 = blockIdx.y * 16;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
     const int K = P.K;
+    const bool ln = P.ln_g != nullptr;
 
-    // column base of each of this workgroup's NT tiles
     int nbase[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -112,53 +102,87 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
         else nbase[t] = (tile * NT + t) * 16;
     }
 
-    const bool ln = P.ln_g != nullptr;
-    if (ln) {
-        tile_row_stats(P.X, P.ldx, m0, L.M, K, s_mean, s_rstd);
-        __syncthreads();
-    }
-    const float mean = ln ? s_mean[r] : 0.f, rstd = ln ? s_rstd[r] : 1.f;
-
+    // ---- issue every load up front ----
     const float* xrow = P.X + (int64_t)min(m0 + r, L.M - 1) * P.ldx + q * 8;
     const float* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wrow[t] = P.W + (int64_t)min(nbase[t] + r, P.N - 1) * P.ldw + q * 8;
 
+    float a[CH][8], b[CH][NT][8], g[CH][8], e[CH][8];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int kc = (c * 4 + wave) * 32;
+        if (kc < K) {
+            load8(xrow + kc, a[c]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) load8(wrow[t] + kc, b[c][t]);
+            if (ln) { load8(P.ln_g + kc + q * 8, g[c]); load8(P.ln_b + kc + q * 8, e[c]); }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) a[c][s] = 0.f;
+        }
+    }
+    if (EPI == EPI_STORE && P.tab != nullptr) {
+        for (int i = threadIdx.x; i < 16 * L.latents; i += 256) {
+            const int row = i / L.latents, l = i - row * L.latents;
+            s_zi[row][l] = L.zidx[(int64_t)min(m0 + row, L.M - 1) * L.ldz + l];
+        }
+    }
+
+#ifdef DRM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+#endif
+    // ---- LayerNorm + SiLU of the producing layer, from the fragments in registers ----
+    if (ln) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += a[c][i];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q == 0) s_red[0][wave][r] = s;
+        __syncthreads();
+        const float mean = ((s_red[0][0][r] + s_red[0][1][r]) + (s_red[0][2][r] + s_red[0][3][r])) / (float)K;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float d = a[c][i] - mean; v += d * d; }
+            }
+        }
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (q == 0) s_red[1][wave][r] = v;
+        __syncthreads();
+        const float var = ((s_red[1][0][r] + s_red[1][1][r]) + (s_red[1][2][r] + s_red[1][3][r])) / (float)K;
+        const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[c][i] = silu_f((a[c][i] - mean) * rstd * g[c][i] + e[c][i]);
+            }
+        }
+    }
+
+#ifdef DRM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP();
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll 2
-    for (int kc = wave * 32; kc < K; kc += 128) {
-        float a[8];
-        {
-            const float4 a0 = *reinterpret_cast<const float4*>(xrow + kc);
-            const float4 a1 = *reinterpret_cast<const float4*>(xrow + kc + 4);
-            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
-            a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-        }
-        float b[NT][8];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 b0 = *reinterpret_cast<const float4*>(wrow[t] + kc);
-            const float4 b1 = *reinterpret_cast<const float4*>(wrow[t] + kc + 4);
-            b[t][0] = b0.x; b[t][1] = b0.y; b[t][2] = b0.z; b[t][3] = b0.w;
-            b[t][4] = b1.x; b[t][5] = b1.y; b[t][6] = b1.z; b[t][7] = b1.w;
-        }
-        if (ln) {
-            const float4 g0 = *reinterpret_cast<const float4*>(P.ln_g + kc + q * 8);
-            const float4 g1 = *reinterpret_cast<const float4*>(P.ln_g + kc + q * 8 + 4);
-            const float4 e0 = *reinterpret_cast<const float4*>(P.ln_b + kc + q * 8);
-            const float4 e1 = *reinterpret_cast<const float4*>(P.ln_b + kc + q * 8 + 4);
-            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    for (int c = 0; c < CH; ++c) {
+        if ((c * 4 + wave) * 32 < K) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) a[s] = silu_f((a[s] - mean) * rstd * g[s] + e[s]);
-        }
+            for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s], b[c][t][s], acc[t], 0, 0, 0);
         }
     }
 
@@ -167,8 +191,11 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_part[wave][t][q * 4 + i][r] = acc[t][i];
+    STAMP();
     __syncthreads();
+    STAMP();
 
+    STAMP_FLUSH((unsigned long long)(EPI * 100 + NT * 10 + (ln ? 1 : 0)));
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
     const int m = m0 + row;
     float v[NT];
@@ -184,9 +211,16 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
             if (n >= P.N) continue;
             float y = v[t] + (P.bias ? P.bias[n] : 0.f);
             if (P.tab != nullptr) {
-                const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
-                for (int l = 0; l < L.latents; ++l)
-                    y += P.tab[(int64_t)(l * L.classes + zi[l]) * P.ldt + n];
+                const float* tb = P.tab + n;
+                int l = 0;
+                for (; l + 8 <= L.latents; l += 8) {   // eight independent row reads in flight
+                    float u[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) u[i] = tb[(int64_t)((l + i) * L.classes + s_zi[row][l + i]) * P.ldt];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y += u[i];
+                }
+                for (; l < L.latents; ++l) y += tb[(int64_t)(l * L.classes + s_zi[row][l]) * P.ldt];
             }
             P.Y[(int64_t)m * P.ldy + n] = y;
         }
@@ -195,26 +229,24 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
         const int j = tile * 16 + col;
         if (j >= G.D) return;
         const float* gh = G.gh + (int64_t)m * G.ldgh;
-        const float gr = v[0] + G.b_ih[j] + gh[j];
-        const float gu = v[1] + G.b_ih[G.D + j] + gh[G.D + j];
-        const float rr = sigmoid_f(gr), uu = sigmoid_f(gu);
-        const float nn = tanhf((v[2] + G.b_ih[2 * G.D + j]) + rr * gh[2 * G.D + j]);
+        const float ghr = gh[j], ghu = gh[G.D + j], ghn = gh[2 * G.D + j];
+        const float bir = G.b_ih[j], biu = G.b_ih[G.D + j], bin = G.b_ih[2 * G.D + j];
         const float hp = G.h_prev[(int64_t)m * G.ldh + j];
+        const float rr = sigmoid_f(v[0] + bir + ghr), uu = sigmoid_f(v[1] + biu + ghu);
+        const float nn = tanhf((v[2] + bin) + rr * ghn);
         G.h_new[(int64_t)m * G.ldhn + j] = (1.0f - uu) * nn + uu * hp;
     } else {  // EPI_SAMPLE: NT == 2, this workgroup holds the 32 logits of latent `tile` for 16 rows
         const int lat = tile;
         const int mm = min(m, L.M - 1);
+        const float* ex = S.expo + (int64_t)mm * S.lde + lat * 32;
+        const float e0 = ex[col], e1 = ex[16 + col];
         float lg[2], sc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) lg[t] = v[t] + P.bias[lat * 32 + t * 16 + col];
         const float mx = group_max<16>(fmaxf(lg[0], lg[1]));
         const float lse = logf(group_sum<16>(expf(lg[0] - mx) + expf(lg[1] - mx)));
-        const float* ex = S.expo + (int64_t)mm * S.lde + lat * 32;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float lp = logaddexp_f((lg[t] - mx - lse) + S.log1m_eps, S.log_eps_over_k);
-            sc[t] = lp - logf(ex[t * 16 + col]);
-        }
+        sc[0] = logaddexp_f((lg[0] - mx - lse) + S.log1m_eps, S.log_eps_over_k) - logf(e0);
+        sc[1] = logaddexp_f((lg[1] - mx - lse) + S.log1m_eps, S.log_eps_over_k) - logf(e1);
         const float smax = group_max<16>(fmaxf(sc[0], sc[1]));
         float y0 = expf(sc[0] - smax), y1 = expf(sc[1] - smax);
         const float ssum = group_sum<16>(y0 + y1);
@@ -241,5 +273,8 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
         }
     }
 }
+
+// CH (chunks of 32 per wave) for a K: 1, 2 or 4; K > 512 is not built
+inline int chunks_for(int K) { return K <= 128 ? 1 : (K <= 256 ? 2 : 4); }
 
 }  // namespace drm

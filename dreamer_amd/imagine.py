@@ -54,6 +54,7 @@ class ImagineEngine:
         self.pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
         self._ws = None
         self._ws_key = None
+        self._slots = {}
         self.repack()
 
     def _weights(self) -> N.drm_imagine_weights:
@@ -87,23 +88,8 @@ class ImagineEngine:
             self._ws_key = (B, H)
         return self._ws
 
-    @torch.no_grad()
-    def run(self, start: WorldModelState, horizon: int, gamma: float, lam: float,
-            noise: Optional[Dict[str, torch.Tensor]] = None, forced_actions: Optional[torch.Tensor] = None,
-            forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
-            want_prior_logits: bool = False, want_sampled: bool = False, start_zidx: Optional[torch.Tensor] = None,
-            repack: bool = True) -> Dict[str, torch.Tensor]:
+    def _alloc_outputs(self, B, H, want_dense_z, want_logp, want_prior_logits, want_sampled):
         d, dev = self.dims, self.device
-        B, H = start.h.shape[0], int(horizon)
-        if repack:
-            self.repack()
-        h0 = start.h.detach().contiguous().float()
-        zidx0 = start_zidx if start_zidx is not None else N.onehot_to_index(start.z.detach().contiguous().float())
-        if noise is None:
-            noise = {"a": torch.empty(H, B, d.A, device=dev).exponential_(),
-                     "z": torch.empty(H, B, d.L, d.K, device=dev).exponential_()}
-        ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
-        assert ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K)
         f32 = dict(dtype=torch.float32, device=dev)
         out = {
             "h": torch.empty(B, H, d.D, **f32), "zidx": torch.empty(B, H, d.L, dtype=torch.uint8, device=dev),
@@ -120,6 +106,48 @@ class ImagineEngine:
         if want_sampled:
             out["zidx_sampled"] = torch.empty(B, H, d.L, dtype=torch.uint8, device=dev)
             out["actions_sampled"] = torch.empty(B, H, dtype=torch.int64, device=dev)
+        return out
+
+    @torch.no_grad()
+    def run(self, start: WorldModelState, horizon: int, gamma: float, lam: float,
+            noise: Optional[Dict[str, torch.Tensor]] = None, forced_actions: Optional[torch.Tensor] = None,
+            forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
+            want_prior_logits: bool = False, want_sampled: bool = False, start_zidx: Optional[torch.Tensor] = None,
+            repack: bool = True, persistent: bool = False) -> Dict[str, torch.Tensor]:
+        """Run the block.  With ``persistent=True`` all inputs are staged into, and all outputs
+        returned as, buffers that live as long as the engine (overwritten by the next call with the
+        same shape); every device address is then the same from call to call and the native side
+        replays the block as one recorded hipGraph."""
+        d, dev = self.dims, self.device
+        B, H = start.h.shape[0], int(horizon)
+        if repack:
+            self.repack()
+        flags = (want_dense_z, want_logp, want_prior_logits, want_sampled)
+        slot = self._slots.get((B, H, flags)) if persistent else None
+        if slot is None:
+            slot = {"out": self._alloc_outputs(B, H, *flags)}
+            if persistent:
+                slot.update(h0=torch.empty(B, d.D, device=dev), zidx0=torch.empty(B, d.L, dtype=torch.uint8, device=dev),
+                            ea=torch.empty(H, B, d.A, device=dev), ez=torch.empty(H, B, d.L, d.K, device=dev))
+                self._slots[(B, H, flags)] = slot
+        out = slot["out"]
+        h0 = start.h.detach()
+        zidx0 = start_zidx if start_zidx is not None else N.onehot_to_index(start.z.detach().contiguous().float())
+        if persistent:
+            slot["h0"].copy_(h0)
+            slot["zidx0"].copy_(zidx0)
+            h0, zidx0 = slot["h0"], slot["zidx0"]
+            if noise is None:
+                ea, ez = slot["ea"].exponential_(), slot["ez"].exponential_()
+            else:
+                ea, ez = slot["ea"].copy_(noise["a"]), slot["ez"].copy_(noise["z"])
+        else:
+            h0 = h0.contiguous().float()
+            if noise is None:
+                noise = {"a": torch.empty(H, B, d.A, device=dev).exponential_(),
+                         "z": torch.empty(H, B, d.L, d.K, device=dev).exponential_()}
+            ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
+        assert ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K)
         ws = self._workspace(B, H)
         io = N.drm_imagine_io()
         io.B, io.H = B, H
@@ -135,6 +163,7 @@ class ImagineEngine:
         io.v_last_out, io.lam_returns_out = out["v_last"].data_ptr(), out["lam_returns"].data_ptr()
         io.gamma, io.lam = float(gamma), float(lam)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        io.use_graph = 1 if (persistent and forced_actions is None and forced_zidx is None) else 0
         w = self._weights()
         N.check(N.lib().drm_imagine_block_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_imagine_block_f32")
         return out

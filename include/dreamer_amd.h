@@ -103,7 +103,7 @@ int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint8_t* idx_ou
  *   normalisation applied by the consumer of the raw pre-activations);
  *   the table term (optional) is the one-hot part of a Linear over cat[h, z_flat]
  *   (lib/world_model.py:213-215) written as a row gather.
- * W is (N,K) row-major with row stride ldw (torch Linear layout).  K % 32 == 0. */
+ * W is (N,K) row-major with row stride ldw (torch Linear layout).  K % 32 == 0, K <= 512. */
 typedef struct drm_linear_args {
     const float* X; int64_t ldx;
     const float* ln_gamma; const float* ln_beta;
@@ -134,11 +134,11 @@ typedef struct drm_mlp {
 } drm_mlp;
 
 typedef struct drm_dims {
-    int32_t D;   /* recurrent width (hidden_size) */
+    int32_t D;   /* recurrent width (hidden_size): multiple of 32, <= 512 */
     int32_t L;   /* latents */
     int32_t K;   /* classes per latent: must be 32 */
-    int32_t M;   /* mlp_hidden_units */
-    int32_t A;   /* actions (<= 64) */
+    int32_t M;   /* mlp_hidden_units: multiple of 32, <= 512 */
+    int32_t A;   /* actions (<= 32) */
     int32_t E;   /* action embedding width (64) */
     int32_t NB;  /* critic buckets (<= 256) */
     float unimix_eps;
@@ -192,10 +192,15 @@ typedef struct drm_imagine_io {
     float* lam_returns_out;        /* (B,H) */
     double gamma, lam;
     void* workspace; size_t workspace_bytes;
+    int32_t use_graph;             /* != 0: record the launches of this call into a hipGraph the first
+                                      time this exact (weights, io) argument pair is seen and replay the
+                                      graph afterwards (callers keep every buffer at a fixed address) */
 } drm_imagine_io;
 
 size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H);
 int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream);
+/* Destroys the recorded graphs (at most 16 are kept, oldest evicted first). */
+int drm_graph_cache_clear(void);
 
 #ifdef __cplusplus
 }

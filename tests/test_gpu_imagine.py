@@ -99,3 +99,21 @@ def test_large_batch_properties():
     same = torch.equal(part["zidx"].cpu(), ref["z"].argmax(-1).to(torch.uint8)) and torch.equal(part["actions"].cpu(), ref["actions"])
     if same:   # no near-tie among these draws: states must agree to tolerance
         assert rel_err(part["h"].cpu(), ref["h"]) < TOL and rel_err(part["lam_returns"].cpu(), ref["lam_returns"]) < TOL
+
+
+def test_graph_replay_equals_direct_launches():
+    d, salt, B, H = DIMS["default"], 9, 16, 15
+    wm, actor, critic, eng = _engine(d, salt)
+    h0, z0, _ = start_state(d, salt, B)
+    st = WorldModelState(h=h0.to(DEV), z=z0.to(DEV))
+    outs = []
+    for i in range(3):   # call 0 records the graph, calls 1-2 replay it with new noise
+        noise = {"a": torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt + i)).to(DEV),
+                 "z": torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt + i)).to(DEV)}
+        direct = {k: v.clone() for k, v in eng.run(st, H, 0.997, 0.95, noise=noise).items()}
+        replay = eng.run(st, H, 0.997, 0.95, noise=noise, persistent=True)
+        torch.cuda.synchronize()
+        for k in direct:
+            assert torch.equal(direct[k], replay[k]), (i, k)
+        outs.append(direct["h"])
+    assert not torch.equal(outs[0], outs[1])
