@@ -95,6 +95,50 @@ def cpu_baseline(cfg, wm, actor, critic, B, H, budget_s=15.0):
                       f"reference; {os.cpu_count()} logical CPUs visible"}
 
 
+def measure_train(device, world, rank, steps, warmup, fence):
+    """Full training updates (lib/trainer.py:162-247): replay gather, world-model loss + backward,
+    gradient all-reduce, clip, Adam, imagination block, critic and actor updates; per-GPU batch
+    16 x 64 from a synthetic HBM-resident replay ring."""
+    import numpy as np
+    from dreamer_amd.config import Config
+    from dreamer_amd.replay_buffer import ReplayBuffer
+    from dreamer_amd.trainer import Learner
+    cfg = Config(device=device)
+    torch.manual_seed(0)
+    learner = Learner(cfg, (3, 64, 64), 6)
+    with torch.no_grad():
+        for head in (learner.world_model.rew.head, learner.world_model.cont.head, learner.actor.head, learner.critic.head):
+            torch.nn.init.normal_(head.weight, std=0.05)
+    cap = 8192
+    rng = np.random.default_rng(1234 + rank)
+    buf = ReplayBuffer(cap, (3, 64, 64), cfg.batch_length, device)
+    buf.store_many(rng.integers(0, 256, size=(cap, 3, 64, 64), dtype=np.uint8), rng.integers(0, 6, size=cap),
+                   rng.standard_normal(cap).astype(np.float32), rng.random(cap) > 0.01)
+    np.random.seed(42 + rank)
+
+    def step():
+        return learner.update(buf.sample(cfg.batch_size, want_f32=True))
+
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out["world_model_loss"]).all()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ups = steps / dt
+    return {"updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
+            "replayed_steps_per_sec": ups * world * cfg.batch_size * cfg.batch_length, "steps": steps, "warmup": warmup,
+            "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +147,7 @@ def main():
     ap.add_argument("--workload", default="imagine16", choices=["imagine16", "imagine4096"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=20, help="full training updates to time as well (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,6 +223,10 @@ def main():
                         kernels={k: {"us_per_step": v["ms"] * 1e3 / args.profile_steps, "launches_per_step": v["launches"] / args.profile_steps}
                                  for k, v in summ.items()})
 
+    train = None
+    if args.train_steps > 0:
+        train = measure_train(device, world, rank, args.train_steps, 3, fence)
+
     if rank == 0:
         value = world * B * H * args.steps / elapsed
         line = {
@@ -189,6 +238,7 @@ def main():
                        "B_per_gpu": B, "H": H},
             "algorithmic_tflops": value * FLOP_PER_LATENT_STEP / 1e12,
             "roofline": roofline,
+            "train": train,
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, wm, actor, critic, 16, H)

@@ -68,6 +68,21 @@ class drm_imagine_io(C.Structure):
                 ("workspace_bytes", C.c_size_t), ("use_graph", C.c_int32)]
 
 
+class drm_observe_weights(C.Structure):
+    _fields_ = [("dims", drm_dims), ("a_emb", C.c_void_p), ("lin_w", C.c_void_p), ("lin_b", C.c_void_p),
+                ("gru_w_ih", C.c_void_p), ("gru_w_hh", C.c_void_p), ("gru_b_ih", C.c_void_p), ("gru_b_hh", C.c_void_p),
+                ("fc_w_h", C.c_void_p), ("ld_fc", C.c_int64), ("pack", C.c_void_p), ("pack_bytes", C.c_size_t)]
+
+
+class drm_observe_io(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("h0", C.c_void_p), ("zidx0", C.c_void_p), ("a_prev", C.c_void_p),
+                ("c_prev", C.c_void_p), ("expo_reset", C.c_void_p), ("expo_z", C.c_void_p), ("e_part", C.c_void_p),
+                ("h_out", C.c_void_p), ("zidx_out", C.c_void_p), ("zidx_in_out", C.c_void_p), ("z_out", C.c_void_p),
+                ("post_out", C.c_void_p), ("y_out", C.c_void_p), ("gates_out", C.c_void_p), ("x_out", C.c_void_p),
+                ("h_in_out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("use_graph", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/dreamer_amd.h declares
 SIGNATURES = {
     "drm_version": (C.c_int, []),
@@ -88,6 +103,10 @@ SIGNATURES = {
     "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
     "drm_imagine_block_f32": (C.c_int, [C.POINTER(drm_imagine_weights), C.POINTER(drm_imagine_io), C.c_void_p]),
     "drm_graph_cache_clear": (C.c_int, []),
+    "drm_pack_observe_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
+    "drm_pack_observe": (C.c_int, [C.POINTER(drm_observe_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "drm_observe_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
+    "drm_observe_forward_f32": (C.c_int, [C.POINTER(drm_observe_weights), C.POINTER(drm_observe_io), C.c_void_p]),
 }
 
 

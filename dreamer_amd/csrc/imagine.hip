@@ -2,7 +2,7 @@
 // lambda-return) as a chain of fused-linear launches.  Every layer boundary is an all-to-all over
 // the feature dimension (LayerNorm and the next matmul need whole rows), so each is a kernel
 // boundary; inside a kernel the output columns are spread over the CUs.
-#include "linear16.hpp"
+#include "launch.hpp"
 
 #include <cstring>
 #include <mutex>
@@ -253,99 +253,6 @@ __global__ __launch_bounds__(256) void k_critic_value(const float* __restrict__ 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// host-side launch helpers
-// ------------------------------------------------------------------------------------------------
-struct ProblemSpec {
-    const float* X; int64_t ldx; const float* ln_g; const float* ln_b;
-    const float* W; int64_t ldw; const float* bias; const float* tab; int64_t ldt;
-    float* Y; int64_t ldy; int N, K;
-};
-
-static int check_problem(const ProblemSpec& s) {
-    DRM_REQUIRE(s.X && s.W && s.Y, DRM_EINVAL, "null pointer in linear problem");
-    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0 && s.K <= 512, DRM_ENOTSUP, "K=%d must be a multiple of 32 in [32, 512]", s.K);
-    DRM_REQUIRE(s.N >= 1, DRM_EINVAL, "N=%d", s.N);
-    DRM_REQUIRE(aligned16(s.X) && aligned16(s.W) && s.ldx % 4 == 0 && s.ldw % 4 == 0, DRM_EINVAL,
-                "X/W must be 16-byte aligned with row strides a multiple of 4 floats");
-    DRM_REQUIRE(!s.ln_g || (s.ln_b && aligned16(s.ln_g) && aligned16(s.ln_b)), DRM_EINVAL, "bad LayerNorm pointers");
-    return DRM_OK;
-}
-
-static int launch_store(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents,
-                        int classes, hipStream_t stream) {
-    DRM_REQUIRE(np >= 1 && np <= MAX_PROBLEMS && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
-    LinLaunch L{};
-    int tiles = 0;
-    for (int i = 0; i < np; ++i) {
-        if (int rc = check_problem(specs[i])) return rc;
-        DRM_REQUIRE(!specs[i].tab || zidx, DRM_EINVAL, "gather table without indices");
-        LinProblem& p = L.p[i];
-        p.X = specs[i].X; p.ldx = specs[i].ldx; p.ln_g = specs[i].ln_g; p.ln_b = specs[i].ln_b;
-        p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.tab = specs[i].tab; p.ldt = specs[i].ldt;
-        p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.tile_begin = tiles;
-        tiles += (specs[i].N + 15) / 16;
-    }
-    L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
-    double fl = 0, by = 0;
-    for (int i = 0; i < np; ++i) {
-        const double n = specs[i].N, k = specs[i].K, m = M;
-        fl += 2.0 * m * n * k + (specs[i].tab ? (double)latents * m * n : 0.0);
-        by += 4.0 * (m * k + n * k + n + m * n) + (specs[i].tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
-    }
-    DRM_REQUIRE(latents <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", latents, MAX_LATENTS);
-    int kmax = 0;
-    for (int i = 0; i < np; ++i) kmax = specs[i].K > kmax ? specs[i].K : kmax;
-    ProfScope prof(PC_LINEAR, stream, fl, by);
-    const dim3 grid(tiles, (M + 15) / 16), block(256);
-    switch (chunks_for(kmax)) {
-        case 1: k_linear16<1, EPI_STORE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
-        case 2: k_linear16<1, EPI_STORE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
-        default: k_linear16<1, EPI_STORE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
-    }
-    DRM_LAUNCH_CHECK();
-    return DRM_OK;
-}
-
-static int launch_gru(const ProblemSpec& spec, int M, const GruEpilogue& G, hipStream_t stream) {
-    if (int rc = check_problem(spec)) return rc;
-    DRM_REQUIRE(spec.N == 3 * G.D && G.D % 16 == 0, DRM_ENOTSUP, "GRU width %d", G.D);
-    LinLaunch L{};
-    LinProblem& p = L.p[0];
-    p.X = spec.X; p.ldx = spec.ldx; p.W = spec.W; p.ldw = spec.ldw; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
-    L.np = 1; L.M = M;
-    ProfScope prof(PC_GRU, stream, 2.0 * M * spec.N * spec.K + 12.0 * M * G.D,
-                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + 5.0 * M * G.D + M * G.D));
-    const dim3 grid(G.D / 16, (M + 15) / 16), block(256);
-    switch (chunks_for(spec.K)) {
-        case 1: k_linear16<3, EPI_GRU, 1><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
-        case 2: k_linear16<3, EPI_GRU, 2><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
-        default: k_linear16<3, EPI_GRU, 4><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
-    }
-    DRM_LAUNCH_CHECK();
-    return DRM_OK;
-}
-
-static int launch_sample(const ProblemSpec& spec, int M, int latents, const SampleEpilogue& S, hipStream_t stream) {
-    if (int rc = check_problem(spec)) return rc;
-    DRM_REQUIRE(spec.N == latents * 32 && spec.bias, DRM_EINVAL, "sampling head must have N = 32*latents and a bias");
-    LinLaunch L{};
-    LinProblem& p = L.p[0];
-    p.X = spec.X; p.ldx = spec.ldx; p.ln_g = spec.ln_g; p.ln_b = spec.ln_b; p.W = spec.W; p.ldw = spec.ldw;
-    p.bias = spec.bias; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
-    L.np = 1; L.M = M;
-    ProfScope prof(PC_DYN_SAMPLE, stream, 2.0 * M * spec.N * spec.K,
-                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + (double)M * spec.N) + (double)M * latents);
-    const dim3 grid(latents, (M + 15) / 16), block(256);
-    switch (chunks_for(spec.K)) {
-        case 1: k_linear16<2, EPI_SAMPLE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
-        case 2: k_linear16<2, EPI_SAMPLE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
-        default: k_linear16<2, EPI_SAMPLE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
-    }
-    DRM_LAUNCH_CHECK();
-    return DRM_OK;
-}
-
 static int check_dims(const drm_dims& d) {
     DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
     DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0 && d.D <= 512 && d.M <= 512, DRM_ENOTSUP,
@@ -530,7 +437,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
         float* h_new = io->h_out + (size_t)t * D;
         {
             ProblemSpec p{ws + wl.x, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, h_new, (int64_t)H * D, 3 * D, D};
-            GruEpilogue G{w->gru_b_ih, ws + wl.gh, 3 * D, h_t, ldh, h_new, (int64_t)H * D, D};
+            GruEpilogue G{w->gru_b_ih, ws + wl.gh, 3 * D, h_t, ldh, h_new, (int64_t)H * D, D, nullptr, 0, nullptr, nullptr, 0};
             if (int rc = launch_gru(p, B, G, s)) return rc;
         }
         // dyn layer 1 and (for the next step) gh = W_hh h_{t+1} + b_hh share their input

@@ -1,0 +1,118 @@
+// Host-side launch helpers for the small-row fused linear kernels (shared by the imagination and
+// observe drivers).
+#pragma once
+#include "linear16.hpp"
+
+namespace drm {
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------------
+struct ProblemSpec {
+    const float* X; int64_t ldx; const float* ln_g; const float* ln_b;
+    const float* W; int64_t ldw; const float* bias; const float* tab; int64_t ldt;
+    float* Y; int64_t ldy; int N, K;
+};
+
+static inline int check_problem(const ProblemSpec& s) {
+    DRM_REQUIRE(s.X && s.W && s.Y, DRM_EINVAL, "null pointer in linear problem");
+    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0 && s.K <= 512, DRM_ENOTSUP, "K=%d must be a multiple of 32 in [32, 512]", s.K);
+    DRM_REQUIRE(s.N >= 1, DRM_EINVAL, "N=%d", s.N);
+    DRM_REQUIRE(aligned16(s.X) && aligned16(s.W) && s.ldx % 4 == 0 && s.ldw % 4 == 0, DRM_EINVAL,
+                "X/W must be 16-byte aligned with row strides a multiple of 4 floats");
+    DRM_REQUIRE(!s.ln_g || (s.ln_b && aligned16(s.ln_g) && aligned16(s.ln_b)), DRM_EINVAL, "bad LayerNorm pointers");
+    return DRM_OK;
+}
+
+static inline int launch_store(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents,
+                        int classes, hipStream_t stream) {
+    DRM_REQUIRE(np >= 1 && np <= MAX_PROBLEMS && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
+    LinLaunch L{};
+    int tiles = 0;
+    for (int i = 0; i < np; ++i) {
+        if (int rc = check_problem(specs[i])) return rc;
+        DRM_REQUIRE(!specs[i].tab || zidx, DRM_EINVAL, "gather table without indices");
+        LinProblem& p = L.p[i];
+        p.X = specs[i].X; p.ldx = specs[i].ldx; p.ln_g = specs[i].ln_g; p.ln_b = specs[i].ln_b;
+        p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.tab = specs[i].tab; p.ldt = specs[i].ldt;
+        p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.tile_begin = tiles;
+        tiles += (specs[i].N + 15) / 16;
+    }
+    L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
+    double fl = 0, by = 0;
+    for (int i = 0; i < np; ++i) {
+        const double n = specs[i].N, k = specs[i].K, m = M;
+        fl += 2.0 * m * n * k + (specs[i].tab ? (double)latents * m * n : 0.0);
+        by += 4.0 * (m * k + n * k + n + m * n) + (specs[i].tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
+    }
+    DRM_REQUIRE(latents <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", latents, MAX_LATENTS);
+    int kmax = 0;
+    for (int i = 0; i < np; ++i) kmax = specs[i].K > kmax ? specs[i].K : kmax;
+    ProfScope prof(PC_LINEAR, stream, fl, by);
+    const dim3 grid(tiles, (M + 15) / 16), block(256);
+    switch (chunks_for(kmax)) {
+        case 1: k_linear16<1, EPI_STORE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+        case 2: k_linear16<1, EPI_STORE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+        default: k_linear16<1, EPI_STORE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+    }
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+static inline int launch_gru(const ProblemSpec& spec, int M, const GruEpilogue& G, hipStream_t stream) {
+    if (int rc = check_problem(spec)) return rc;
+    DRM_REQUIRE(spec.N == 3 * G.D && G.D % 16 == 0, DRM_ENOTSUP, "GRU width %d", G.D);
+    LinLaunch L{};
+    LinProblem& p = L.p[0];
+    p.X = spec.X; p.ldx = spec.ldx; p.W = spec.W; p.ldw = spec.ldw; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
+    L.np = 1; L.M = M;
+    ProfScope prof(PC_GRU, stream, 2.0 * M * spec.N * spec.K + 12.0 * M * G.D,
+                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + 5.0 * M * G.D + M * G.D));
+    const dim3 grid(G.D / 16, (M + 15) / 16), block(256);
+    switch (chunks_for(spec.K)) {
+        case 1: k_linear16<3, EPI_GRU, 1><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+        case 2: k_linear16<3, EPI_GRU, 2><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+        default: k_linear16<3, EPI_GRU, 4><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+    }
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+// `extra` (optional): a second GEMM with the plain store epilogue that shares the launch (its tiles are
+// 32 columns wide); used for gh = W_hh h, which consumes the same freshly written h as the logits.
+static inline int launch_sample(const ProblemSpec& spec, int M, int latents, const SampleEpilogue& S, hipStream_t stream,
+                                const ProblemSpec* extra = nullptr) {
+    if (int rc = check_problem(spec)) return rc;
+    if (extra) { if (int rc = check_problem(*extra)) return rc; }
+    DRM_REQUIRE(spec.N == latents * 32, DRM_EINVAL, "sampling head must have N = 32*latents");
+    LinLaunch L{};
+    LinProblem& p = L.p[0];
+    p.X = spec.X; p.ldx = spec.ldx; p.ln_g = spec.ln_g; p.ln_b = spec.ln_b; p.W = spec.W; p.ldw = spec.ldw;
+    p.bias = spec.bias; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
+    L.np = 1; L.M = M;
+    int tiles = latents, kmax = spec.K;
+    double xfl = 0, xby = 0;
+    if (extra) {
+        LinProblem& e = L.p[1];
+        e.X = extra->X; e.ldx = extra->ldx; e.ln_g = extra->ln_g; e.ln_b = extra->ln_b; e.W = extra->W; e.ldw = extra->ldw;
+        e.bias = extra->bias; e.Y = extra->Y; e.ldy = extra->ldy; e.N = extra->N; e.K = extra->K; e.tile_begin = latents;
+        L.np = 2;
+        tiles += (extra->N + 31) / 32;
+        kmax = extra->K > kmax ? extra->K : kmax;
+        xfl = 2.0 * M * extra->N * extra->K;
+        xby = 4.0 * ((double)M * extra->K + (double)extra->N * extra->K + extra->N + (double)M * extra->N);
+    }
+    ProfScope prof(PC_DYN_SAMPLE, stream, 2.0 * M * spec.N * spec.K + xfl,
+                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + (double)M * spec.N) + (double)M * latents + xby);
+    const dim3 grid(tiles, (M + 15) / 16), block(256);
+    switch (chunks_for(kmax)) {
+        case 1: k_linear16<2, EPI_SAMPLE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+        case 2: k_linear16<2, EPI_SAMPLE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+        default: k_linear16<2, EPI_SAMPLE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+    }
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+
+}  // namespace drm

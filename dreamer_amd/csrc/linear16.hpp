@@ -46,15 +46,21 @@ struct LinLaunch {
     const uint8_t* zidx; int64_t ldz; int latents, classes;   // shared by all problems that gather
 };
 
-struct GruEpilogue {       // h_new = GRU(gi = acc + b_ih, gh (precomputed, bias included), h_prev)
+struct GruEpilogue {       // h_new = GRU(gi = acc + b_ih, gh, h_prev)
     const float* b_ih;     // (3D)
-    const float* gh; int64_t ldgh;   // (M, 3D)
+    const float* gh; int64_t ldgh;   // (M, 3D): W_hh h (+ b_hh when b_hh == nullptr)
     const float* h_prev; int64_t ldh;
     float* h_new; int64_t ldhn;
     int D;
+    // episode-boundary form (observe): gh_eff = row_scale[m] * gh + b_hh, h_prev_eff = row_scale[m] * h_prev
+    const float* row_scale; int64_t ldrs;   // nullptr: no scaling
+    const float* b_hh;                      // nullptr: gh already holds the bias
+    float* gates_out; int64_t ldgo;         // (M, 4D) = r, u, n, gh_n saved for the backward pass, or nullptr
 };
 
 struct SampleEpilogue {    // one latent (32 classes) per workgroup
+    const float* add; int64_t ldadd;         // (M, L*32) added to the logits (hoisted encoder part) or nullptr
+    float* y_out; int64_t ldyo;              // (M, L*32) soft sample probabilities (for the backward pass) or nullptr
     const float* expo; int64_t lde;          // (M, L*32) Exp(1) noise, row stride lde
     const uint8_t* forced; int64_t ldf;      // (M, L) or nullptr
     uint8_t* idx_used; int64_t ldu;          // (M, L)
@@ -229,12 +235,28 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
         const int j = tile * 16 + col;
         if (j >= G.D) return;
         const float* gh = G.gh + (int64_t)m * G.ldgh;
-        const float ghr = gh[j], ghu = gh[G.D + j], ghn = gh[2 * G.D + j];
+        float ghr = gh[j], ghu = gh[G.D + j], ghn = gh[2 * G.D + j];
         const float bir = G.b_ih[j], biu = G.b_ih[G.D + j], bin = G.b_ih[2 * G.D + j];
-        const float hp = G.h_prev[(int64_t)m * G.ldh + j];
+        float hp = G.h_prev[(int64_t)m * G.ldh + j];
+        if (G.row_scale != nullptr) {
+            const float rs = G.row_scale[(int64_t)m * G.ldrs];
+            ghr *= rs; ghu *= rs; ghn *= rs; hp *= rs;
+        }
+        if (G.b_hh != nullptr) { ghr += G.b_hh[j]; ghu += G.b_hh[G.D + j]; ghn += G.b_hh[2 * G.D + j]; }
         const float rr = sigmoid_f(v[0] + bir + ghr), uu = sigmoid_f(v[1] + biu + ghu);
         const float nn = tanhf((v[2] + bin) + rr * ghn);
         G.h_new[(int64_t)m * G.ldhn + j] = (1.0f - uu) * nn + uu * hp;
+        if (G.gates_out != nullptr) {
+            float* go = G.gates_out + (int64_t)m * G.ldgo;
+            go[j] = rr; go[G.D + j] = uu; go[2 * G.D + j] = nn; go[3 * G.D + j] = ghn;
+        }
+    } else if (&P != &L.p[0]) {  // EPI_SAMPLE launch, companion problem: plain store of a 16 x 32 tile
+        if (m >= L.M) return;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = nbase[t] + col;
+            if (n < P.N) P.Y[(int64_t)m * P.ldy + n] = v[t] + (P.bias ? P.bias[n] : 0.f);
+        }
     } else {  // EPI_SAMPLE: NT == 2, this workgroup holds the 32 logits of latent `tile` for 16 rows
         const int lat = tile;
         const int mm = min(m, L.M - 1);
@@ -242,7 +264,10 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
         const float e0 = ex[col], e1 = ex[16 + col];
         float lg[2], sc[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) lg[t] = v[t] + P.bias[lat * 32 + t * 16 + col];
+        for (int t = 0; t < 2; ++t) {
+            lg[t] = v[t] + (P.bias ? P.bias[lat * 32 + t * 16 + col] : 0.f);
+            if (S.add != nullptr) lg[t] += S.add[(int64_t)mm * S.ldadd + lat * 32 + t * 16 + col];
+        }
         const float mx = group_max<16>(fmaxf(lg[0], lg[1]));
         const float lse = logf(group_sum<16>(expf(lg[0] - mx) + expf(lg[1] - mx)));
         sc[0] = logaddexp_f((lg[0] - mx - lse) + S.log1m_eps, S.log_eps_over_k) - logf(e0);
@@ -270,6 +295,11 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
             float* lo = S.logits_out + (int64_t)m * S.ldlo + lat * 32;
             lo[col] = lg[0];
             lo[16 + col] = lg[1];
+        }
+        if (S.y_out) {
+            float* yo = S.y_out + (int64_t)m * S.ldyo + lat * 32;
+            yo[col] = y0;
+            yo[16 + col] = y1;
         }
     }
 }

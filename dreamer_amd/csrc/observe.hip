@@ -1,0 +1,267 @@
+// Observe (posterior) recurrence over a replayed (B, T) batch: three launches per time step.
+//   k_observe_reset_x : episode-boundary reset, one-hot row gather of the GRU input x
+//   k_linear16<3,GRU> : gi = W_ih x on MFMA + gate combine with the precomputed W_hh h  -> h_t
+//   k_linear16<2,SAMPLE> (+ companion store problem): posterior logits = e_part + W_fc_h h_t, unimix,
+//                       Gumbel-argmax draw of z_t; and gh_raw = W_hh h_t for the next step
+#include "launch.hpp"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace drm {
+
+struct ResetArgs {
+    const float* h_prev; int64_t ldh;
+    const uint8_t* z_prev; int64_t ldz;
+    const int64_t* a_prev; int64_t lda;
+    const float* c_prev; int64_t ldc;
+    const float* expo;                     // (B, L*32) reset noise of this step
+    const float* lin_zT; const float* lin_b; const float* a_tab;
+    int D, L, classes;
+    uint8_t* z_in; int64_t ldzi;
+    float* h_in; int64_t ldhi;
+    float* x; int64_t ldxo;
+};
+
+// One workgroup per sequence.  D <= 512: a thread owns at most two columns.
+template <int LMAX>
+__global__ __launch_bounds__(256) void k_observe_reset_x(const ResetArgs P) {
+    __shared__ uint8_t s_z[LMAX];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float c = P.c_prev[(int64_t)b * P.ldc];
+    const int a = (int)P.a_prev[(int64_t)b * P.lda];
+    const int i0 = tid, i1 = tid + 256;
+    const bool jn0 = i0 < P.D, jn1 = i1 < P.D;
+    const float hp0 = jn0 ? P.h_prev[(int64_t)b * P.ldh + i0] : 0.f, hp1 = jn1 ? P.h_prev[(int64_t)b * P.ldh + i1] : 0.f;
+    const float at0 = jn0 ? P.a_tab[(int64_t)a * P.D + i0] : 0.f, at1 = jn1 ? P.a_tab[(int64_t)a * P.D + i1] : 0.f;
+    float xz0 = jn0 ? P.lin_b[i0] : 0.f, xz1 = jn1 ? P.lin_b[i1] : 0.f;
+    if (c != 0.f) {
+        if (tid < P.L) s_z[tid] = P.z_prev[(int64_t)b * P.ldz + tid];
+    } else {
+        // fresh uniform one-hot: argmax softmax(1/K - log E), eight lanes per latent
+        const int sub = tid & 7;
+        for (int l = tid >> 3; l < P.L; l += 32) {
+            const float4 ex = *reinterpret_cast<const float4*>(P.expo + ((int64_t)b * P.L + l) * 32 + sub * 4);
+            const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (1.0f / 32.0f) - logf(e[j]);
+            const float smax = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            float y[4], s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { y[j] = expf(v[j] - smax); s += y[j]; }
+            s = group_sum<8>(s);
+            float best = -1.f;
+            int bi = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = y[j] / s;
+                if (y[j] > best) { best = y[j]; bi = sub * 4 + j; }
+            }
+            group_argmax<8>(best, bi);
+            if (sub == 0) s_z[l] = (uint8_t)bi;
+        }
+    }
+    __syncthreads();
+    if (tid < P.L) P.z_in[(int64_t)b * P.ldzi + tid] = s_z[tid];
+    float u0[LMAX], u1[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        const bool ok = l < P.L;
+        const int64_t rowoff = ok ? (int64_t)(l * P.classes + s_z[l]) * P.D : 0;
+        u0[l] = (ok && jn0) ? P.lin_zT[rowoff + i0] : 0.f;
+        u1[l] = (ok && jn1) ? P.lin_zT[rowoff + i1] : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) { xz0 += u0[l]; xz1 += u1[l]; }
+    if (jn0) { P.x[(int64_t)b * P.ldxo + i0] = xz0 + c * at0; P.h_in[(int64_t)b * P.ldhi + i0] = c * hp0; }
+    if (jn1) { P.x[(int64_t)b * P.ldxo + i1] = xz1 + c * at1; P.h_in[(int64_t)b * P.ldhi + i1] = c * hp1; }
+}
+
+// defined in imagine.hip's translation unit as well; both are file-local
+__global__ __launch_bounds__(256) void k_transpose_cols_o(const float* __restrict__ W, int64_t ldw, int col0, int ncols,
+                                                           int nrows, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, c = c0 + tx;
+        tile[i][tx] = (n < nrows && c < ncols) ? W[(int64_t)n * ldw + col0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, n = n0 + tx;
+        if (c < ncols && n < nrows) out[(int64_t)c * nrows + n] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_action_table_o(const float* __restrict__ lin_w, int64_t ldw, int col0, int E,
+                                                         const float* __restrict__ a_emb, int A, int D,
+                                                         float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int a = blockIdx.y;
+    if (j >= D) return;
+    const float* w = lin_w + (int64_t)j * ldw + col0;
+    const float* e = a_emb + (int64_t)a * E;
+    float s = 0.f;
+    for (int i = 0; i < E; ++i) s = fmaf(w[i], e[i], s);
+    out[(int64_t)a * D + j] = s;
+}
+
+static int check_observe_dims(const drm_dims& d) {
+    DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
+    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.D <= 512, DRM_ENOTSUP, "D=%d must be a multiple of 32, at most 512", d.D);
+    DRM_REQUIRE(d.L >= 1 && d.L <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", d.L, MAX_LATENTS);
+    DRM_REQUIRE(d.A >= 1 && d.E >= 1, DRM_EINVAL, "A=%d E=%d", d.A, d.E);
+    return DRM_OK;
+}
+
+struct ObsPack { size_t lin_zT, a_tab, total; };
+static ObsPack obs_pack_layout(const drm_dims& d) {
+    ObsPack p{};
+    p.lin_zT = 0;
+    p.a_tab = (size_t)d.L * d.K * d.D;
+    p.total = (p.a_tab + (size_t)d.A * d.D + 3) & ~(size_t)3;
+    return p;
+}
+
+static int observe_enqueue(const drm_observe_weights* w, const drm_observe_io* io, hipStream_t s) {
+    if (int rc = check_observe_dims(w->dims)) return rc;
+    const drm_dims& d = w->dims;
+    const int B = io->B, T = io->T, D = d.D, L = d.L, LK = d.L * d.K;
+    DRM_REQUIRE(B >= 1 && T >= 1, DRM_EINVAL, "B=%d T=%d", B, T);
+    DRM_REQUIRE(w->lin_b && w->gru_w_ih && w->gru_w_hh && w->gru_b_ih && w->gru_b_hh && w->fc_w_h, DRM_EINVAL, "null weight");
+    const ObsPack pl = obs_pack_layout(d);
+    DRM_REQUIRE(w->pack && w->pack_bytes >= pl.total * sizeof(float), DRM_EINVAL, "weights not packed (drm_pack_observe)");
+    DRM_REQUIRE(io->h0 && io->zidx0 && io->a_prev && io->c_prev && io->expo_reset && io->expo_z && io->e_part && io->h_out &&
+                    io->zidx_out && io->zidx_in_out && io->post_out && io->y_out && io->gates_out && io->x_out && io->h_in_out,
+                DRM_EINVAL, "null io pointer");
+    DRM_REQUIRE(io->workspace && io->workspace_bytes >= (size_t)B * 3 * D * sizeof(float) && aligned16(io->workspace),
+                DRM_EINVAL, "workspace too small or misaligned");
+    DRM_REQUIRE(aligned16(io->expo_reset) && aligned16(io->expo_z) && aligned16(io->e_part), DRM_EINVAL, "misaligned input");
+    float* ghraw = (float*)io->workspace;
+    const float l1m = (float)log1p(-(double)d.unimix_eps);
+    const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
+    const int64_t TD = (int64_t)T * D, TL = (int64_t)T * L, TLK = (int64_t)T * LK;
+
+    {   // gh_raw for step 0 from h0
+        ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D};
+        if (int rc = launch_store(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+    }
+    for (int t = 0; t < T; ++t) {
+        const float* h_prev = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D;
+        const int64_t ldh = t == 0 ? D : TD;
+        const uint8_t* z_prev = t == 0 ? io->zidx0 : io->zidx_out + (size_t)(t - 1) * L;
+        const int64_t ldz = t == 0 ? L : TL;
+        float* x_t = io->x_out + (size_t)t * D;
+        float* hin_t = io->h_in_out + (size_t)t * D;
+        uint8_t* zin_t = io->zidx_in_out + (size_t)t * L;
+        {
+            ResetArgs a{};
+            a.h_prev = h_prev; a.ldh = ldh; a.z_prev = z_prev; a.ldz = ldz;
+            a.a_prev = io->a_prev + t; a.lda = T; a.c_prev = io->c_prev + t; a.ldc = T;
+            a.expo = io->expo_reset + (size_t)t * B * LK;
+            a.lin_zT = w->pack + pl.lin_zT; a.lin_b = w->lin_b; a.a_tab = w->pack + pl.a_tab;
+            a.D = D; a.L = L; a.classes = d.K;
+            a.z_in = zin_t; a.ldzi = TL; a.h_in = hin_t; a.ldhi = TD; a.x = x_t; a.ldxo = TD;
+            ProfScope prof(PC_ACTOR_HEAD, s, (double)B * D * (L + 2), 4.0 * (double)B * D * (L + 4));
+            if (L <= 32) k_observe_reset_x<32><<<dim3(B), dim3(256), 0, s>>>(a);
+            else k_observe_reset_x<64><<<dim3(B), dim3(256), 0, s>>>(a);
+            DRM_LAUNCH_CHECK();
+        }
+        float* h_t = io->h_out + (size_t)t * D;
+        {
+            ProblemSpec p{x_t, TD, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, h_t, TD, 3 * D, D};
+            GruEpilogue G{w->gru_b_ih, ghraw, 3 * D, h_prev, ldh, h_t, TD, D, io->c_prev + t, T, w->gru_b_hh,
+                          io->gates_out + (size_t)t * 4 * D, (int64_t)T * 4 * D};
+            if (int rc = launch_gru(p, B, G, s)) return rc;
+        }
+        {
+            ProblemSpec p{h_t, TD, nullptr, nullptr, w->fc_w_h, w->ld_fc, nullptr, nullptr, 0, ghraw, 0, LK, D};
+            ProblemSpec gh{h_t, TD, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D};
+            SampleEpilogue E{};
+            E.add = io->e_part + (size_t)t * LK; E.ldadd = TLK;
+            E.y_out = io->y_out + (size_t)t * LK; E.ldyo = TLK;
+            E.expo = io->expo_z + (size_t)t * B * LK; E.lde = LK;
+            E.idx_used = io->zidx_out + (size_t)t * L; E.ldu = TL;
+            E.z_dense = io->z_out ? io->z_out + (size_t)t * LK : nullptr; E.ldzd = TLK;
+            E.logits_out = io->post_out + (size_t)t * LK; E.ldlo = TLK;
+            E.log1m_eps = l1m; E.log_eps_over_k = lek;
+            if (int rc = launch_sample(p, B, L, E, s, t + 1 < T ? &gh : nullptr)) return rc;
+        }
+    }
+    return DRM_OK;
+}
+
+struct ObsGraph { std::vector<uint8_t> key; hipGraphExec_t exec; };
+static std::mutex g_obs_mu;
+static std::vector<ObsGraph> g_obs_graphs;
+
+}  // namespace drm
+
+using namespace drm;
+
+extern "C" size_t drm_pack_observe_bytes(const drm_dims* dims) {
+    if (!dims || check_observe_dims(*dims) != DRM_OK) return 0;
+    return obs_pack_layout(*dims).total * sizeof(float);
+}
+
+extern "C" int drm_pack_observe(const drm_observe_weights* w, float* pack_out, size_t pack_bytes, drm_stream_t stream) {
+    DRM_REQUIRE(w && pack_out, DRM_EINVAL, "null pointer");
+    if (int rc = check_observe_dims(w->dims)) return rc;
+    const drm_dims& d = w->dims;
+    const ObsPack pl = obs_pack_layout(d);
+    DRM_REQUIRE(pack_bytes >= pl.total * sizeof(float) && aligned16(pack_out), DRM_EINVAL, "pack buffer too small or misaligned");
+    DRM_REQUIRE(w->lin_w && w->a_emb, DRM_EINVAL, "null weight");
+    hipStream_t s = (hipStream_t)stream;
+    const int LK = d.L * d.K;
+    ProfScope prof(PC_PACK, s, 2.0 * d.A * d.D * d.E, 8.0 * (double)LK * d.D);
+    k_transpose_cols_o<<<dim3((LK + 31) / 32, (d.D + 31) / 32), dim3(256), 0, s>>>(w->lin_w, LK + d.E, 0, LK, d.D,
+                                                                                  pack_out + pl.lin_zT);
+    DRM_LAUNCH_CHECK();
+    k_action_table_o<<<dim3((d.D + 255) / 256, d.A), dim3(256), 0, s>>>(w->lin_w, LK + d.E, LK, d.E, w->a_emb, d.A, d.D,
+                                                                         pack_out + pl.a_tab);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+extern "C" size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, int32_t T) {
+    if (!dims || check_observe_dims(*dims) != DRM_OK || B < 1 || T < 1) return 0;
+    return (size_t)B * 3 * dims->D * sizeof(float);
+}
+
+extern "C" int drm_observe_forward_f32(const drm_observe_weights* w, const drm_observe_io* io, drm_stream_t stream) {
+    DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!io->use_graph || prof_on()) return observe_enqueue(w, io, s);
+    int dev = 0;
+    DRM_HIP(hipGetDevice(&dev));
+    std::vector<uint8_t> key(sizeof(*w) + sizeof(*io) + sizeof(int));
+    memcpy(key.data(), w, sizeof(*w));
+    memcpy(key.data() + sizeof(*w), io, sizeof(*io));
+    memcpy(key.data() + sizeof(*w) + sizeof(*io), &dev, sizeof(int));
+    std::lock_guard<std::mutex> lk(g_obs_mu);
+    for (auto& e : g_obs_graphs)
+        if (e.key == key) { DRM_HIP(hipGraphLaunch(e.exec, s)); return DRM_OK; }
+    static thread_local hipStream_t cap = nullptr;
+    static thread_local int cap_dev = -1;
+    if (cap == nullptr || cap_dev != dev) {
+        DRM_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        cap_dev = dev;
+    }
+    DRM_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    const int rc = observe_enqueue(w, io, cap);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(cap, &graph);
+    if (rc != DRM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    DRM_HIP(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    DRM_HIP(ie);
+    if (g_obs_graphs.size() >= 8) { (void)hipGraphExecDestroy(g_obs_graphs.front().exec); g_obs_graphs.erase(g_obs_graphs.begin()); }
+    g_obs_graphs.push_back(ObsGraph{std::move(key), exec});
+    DRM_HIP(hipGraphLaunch(exec, s));
+    return DRM_OK;
+}

@@ -1,0 +1,81 @@
+"""Data-parallel plumbing: one process per GPU, gradients averaged with ONE collective per model.
+
+Trajectories are independent and every loss is a batch mean, so with equal per-rank batches the
+mean of the ranks' gradients equals the gradient of the global batch.  Each model's gradients live
+in one flat fp32 buffer (parameter ``.grad`` tensors are views into it), so the all-reduce is a
+single RCCL call on a contiguous buffer instead of ~100 small ones, and no copy in or out is needed.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class FlatGrads:
+    """Flat gradient buffer of a module.
+
+    Built after the first backward pass from the parameters that actually received a gradient
+    (``seq.norm.*`` and the critic's frozen ``slow.*`` copy never do; they are left out on every rank
+    alike).  Afterwards ``zero()`` replaces ``optimizer.zero_grad()`` and backward accumulates
+    straight into the buffer.
+    """
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.flat: Optional[torch.Tensor] = None
+        self.params: List[torch.nn.Parameter] = []
+
+    def _build(self) -> None:
+        self.params = [p for p in self.module.parameters() if p.grad is not None]
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        o = 0
+        for p in self.params:
+            view = self.flat[o:o + p.numel()].view_as(p)
+            view.copy_(p.grad)
+            p.grad = view
+            o += p.numel()
+
+    def zero(self) -> None:
+        if self.flat is None:
+            for p in self.module.parameters():
+                p.grad = None
+        else:
+            self.flat.zero_()
+
+    def sync(self) -> None:
+        """Average the gradients over the data-parallel ranks (no-op for a single process)."""
+        if self.flat is None:
+            self._build()
+        if world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world_size())
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
+    """Give every rank rank-``src``'s parameters and buffers (identical replicas at start)."""
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src)
+
+
+def gather_flat(x: torch.Tensor) -> torch.Tensor:
+    """Concatenation over ranks of a flat tensor of equal length on every rank (rank order)."""
+    if world_size() == 1:
+        return x
+    out = torch.empty(world_size() * x.numel(), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous())
+    return out

@@ -8,10 +8,14 @@ Only this part of ``WorldModel.loss`` is sequential in time (lib/world_model.py:
     post   = e_part[t] + enc.fc.weight[:, conv:] @ h     (e_part = hoisted conv features @ W + bias)
     z      = straight-through Gumbel-argmax of log_unimix(post)
 
-``observe_scan`` dispatches on the device of its inputs: HIP tensors go to the fused kernels,
-host tensors to the eager loop below (the reference supports ``device="cpu"`` as well).
+``observe_scan`` dispatches on the device of its inputs: HIP tensors go to the fused kernels
+(``ObserveScanFn``, a torch.autograd.Function: native forward over all T steps, explicit reverse-time
+backward), host tensors to the eager loop (the reference supports ``device="cpu"`` as well).
 """
 from __future__ import annotations
+
+import ctypes as C
+import math
 
 import torch
 import torch.nn.functional as F
@@ -34,6 +38,148 @@ def _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state):
     return torch.stack(hs, 1), torch.stack(zs, 1), torch.stack(posts, 1), WorldModelState(h=h, z=z)
 
 
+class _ObserveEngine:
+    """Packed tables and workspace of one world model for the native scan."""
+
+    def __init__(self, wm):
+        from . import _native as N
+        self.N = N
+        p = wm.seq.linear.weight
+        self.device = p.device
+        self.dims = N.drm_dims(D=wm.hidden_size, L=wm.num_latents, K=wm.classes_per_latent, M=wm.hidden_size,
+                               A=wm.action_size, E=wm.seq.a_emb.embedding_dim, NB=1, unimix_eps=wm.unimix_eps)
+        nbytes = N.lib().drm_pack_observe_bytes(C.byref(self.dims))
+        if nbytes == 0:
+            raise N.NativeError(f"unsupported dimensions: {N.lib().drm_last_error().decode()}")
+        self.pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        self.ws = None
+
+    def weights(self, a_emb, lin_w, lin_b, w_ih, w_hh, b_ih, b_hh, fc_w_h):
+        N = self.N
+        w = N.drm_observe_weights()
+        w.dims = self.dims
+        w.a_emb, w.lin_w, w.lin_b = a_emb.data_ptr(), lin_w.data_ptr(), lin_b.data_ptr()
+        w.gru_w_ih, w.gru_w_hh, w.gru_b_ih, w.gru_b_hh = w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr()
+        w.fc_w_h, w.ld_fc = fc_w_h.data_ptr(), fc_w_h.stride(0)
+        w.pack, w.pack_bytes = self.pack.data_ptr(), self.pack.numel() * 4
+        return w
+
+
+class ObserveScanFn(torch.autograd.Function):
+    """Native forward over all T steps; reverse-time backward from the saved per-step tensors."""
+
+    @staticmethod
+    def forward(ctx, eng, e_part, a_emb, lin_w, lin_b, w_ih, w_hh, b_ih, b_hh, fc_w_h, h0, zidx0, a_prev, c_prev,
+                expo_reset, expo_z):
+        N = eng.N
+        B, T = a_prev.shape
+        d = eng.dims
+        D, L, K = d.D, d.L, d.K
+        dev = e_part.device
+        e_part = e_part.contiguous()
+        w = eng.weights(a_emb, lin_w, lin_b, w_ih, w_hh, b_ih, b_hh, fc_w_h)
+        N.check(N.lib().drm_pack_observe(C.byref(w), eng.pack.data_ptr(), eng.pack.numel() * 4, N.stream_ptr(dev)),
+                "drm_pack_observe")
+        f32 = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        h = torch.empty(B, T, D, **f32); zidx = torch.empty(B, T, L, **u8); zidx_in = torch.empty(B, T, L, **u8)
+        z = torch.empty(B, T, L, K, **f32); post = torch.empty(B, T, L, K, **f32); y = torch.empty(B, T, L, K, **f32)
+        gates = torch.empty(B, T, 4 * D, **f32); x = torch.empty(B, T, D, **f32); h_in = torch.empty(B, T, D, **f32)
+        ws_bytes = N.lib().drm_observe_workspace_bytes(C.byref(d), B, T)
+        if eng.ws is None or eng.ws.numel() * 4 < ws_bytes:
+            eng.ws = torch.empty(ws_bytes // 4 + 4, **f32)
+        io = N.drm_observe_io()
+        io.B, io.T = B, T
+        h0c, c_prev, a_prev = h0.contiguous(), c_prev.contiguous(), a_prev.contiguous()
+        expo_reset, expo_z = expo_reset.contiguous(), expo_z.contiguous()
+        io.h0, io.zidx0, io.a_prev, io.c_prev = h0c.data_ptr(), zidx0.data_ptr(), a_prev.data_ptr(), c_prev.data_ptr()
+        io.expo_reset, io.expo_z, io.e_part = expo_reset.data_ptr(), expo_z.data_ptr(), e_part.data_ptr()
+        io.h_out, io.zidx_out, io.zidx_in_out, io.z_out = h.data_ptr(), zidx.data_ptr(), zidx_in.data_ptr(), z.data_ptr()
+        io.post_out, io.y_out, io.gates_out = post.data_ptr(), y.data_ptr(), gates.data_ptr()
+        io.x_out, io.h_in_out = x.data_ptr(), h_in.data_ptr()
+        io.workspace, io.workspace_bytes = eng.ws.data_ptr(), eng.ws.numel() * 4
+        io.use_graph = 0
+        N.check(N.lib().drm_observe_forward_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_observe_forward_f32")
+        ctx.save_for_backward(a_emb, lin_w, w_ih, w_hh, fc_w_h, a_prev, c_prev, h, zidx_in, post, y, gates, x, h_in)
+        ctx.eps = float(d.unimix_eps)
+        ctx.mark_non_differentiable(zidx)
+        return h, z, post, zidx
+
+    @staticmethod
+    def backward(ctx, g_h, g_z, g_post, _g_zidx):
+        a_emb, lin_w, w_ih, w_hh, fc_w_h, a_prev, c_prev, h, zidx_in, post, y, gates, x, h_in = ctx.saved_tensors
+        B, T, D = h.shape
+        L, K = post.shape[2], post.shape[3]
+        LK = L * K
+        eps = ctx.eps
+        log1m, floor = math.log1p(-eps), math.log(eps) - math.log(K)
+        g_h = torch.zeros_like(h) if g_h is None else g_h
+        g_z = torch.zeros_like(post) if g_z is None else g_z
+        g_post = torch.zeros_like(post) if g_post is None else g_post
+        lin_wz, lin_wa = lin_w[:, :LK], lin_w[:, LK:]
+        # unimix / log-softmax pieces for all steps at once (elementwise, time-parallel)
+        ls = F.log_softmax(post, dim=-1)
+        lp = torch.logaddexp(ls + log1m, ls.new_tensor(floor))
+        w_mix = torch.exp(ls + log1m - lp)
+        p_soft = ls.exp()
+        d_post = torch.empty_like(post)
+        d_gi = torch.empty(B, T, 3 * D, device=h.device, dtype=h.dtype)
+        d_gh = torch.empty_like(d_gi)
+        d_x = torch.empty_like(x)
+        dh_next = torch.zeros(B, D, device=h.device, dtype=h.dtype)
+        dz_next = torch.zeros(B, L, K, device=h.device, dtype=h.dtype)
+        for t in range(T - 1, -1, -1):
+            dz = g_z[:, t] + dz_next
+            yt = y[:, t]
+            dscore = yt * (dz - (yt * dz).sum(-1, keepdim=True))
+            dls = dscore * w_mix[:, t]
+            dp = dls - p_soft[:, t] * dls.sum(-1, keepdim=True) + g_post[:, t]
+            d_post[:, t] = dp
+            dh = g_h[:, t] + dh_next + dp.reshape(B, LK) @ fc_w_h
+            r, u, n, ghn = gates[:, t].split(D, dim=-1)
+            hin = h_in[:, t]
+            dn_pre = dh * (1.0 - u) * (1.0 - n * n)
+            du_pre = dh * (hin - n) * u * (1.0 - u)
+            dr_pre = dn_pre * ghn * r * (1.0 - r)
+            gi = torch.cat([dr_pre, du_pre, dn_pre], dim=-1)
+            gh = torch.cat([dr_pre, du_pre, dn_pre * r], dim=-1)
+            d_gi[:, t], d_gh[:, t] = gi, gh
+            dx = gi @ w_ih
+            d_x[:, t] = dx
+            c = c_prev[:, t:t + 1]
+            dh_next = (dh * u + gh @ w_hh) * c
+            dz_next = (dx @ lin_wz).view(B, L, K) * c.view(B, 1, 1)
+        # weight gradients: one batched product each over all B*T rows
+        gi2, gh2, dx2 = d_gi.reshape(B * T, -1), d_gh.reshape(B * T, -1), d_x.reshape(B * T, D)
+        c2 = c_prev.reshape(B * T, 1)
+        a2 = a_prev.reshape(B * T)
+        z_in = F.one_hot(zidx_in.reshape(B * T, L).long(), K).to(h.dtype).reshape(B * T, LK)
+        a_vec = a_emb[a2] * c2
+        g_w_ih = gi2.t() @ x.reshape(B * T, D)
+        g_w_hh = gh2.t() @ h_in.reshape(B * T, D)
+        g_lin_w = torch.cat([dx2.t() @ z_in, dx2.t() @ a_vec], dim=1)
+        g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, (dx2 @ lin_wa) * c2)
+        g_fc = d_post.reshape(B * T, LK).t() @ h.reshape(B * T, D)
+        return (None, d_post.reshape(B, T, LK), g_a_emb, g_lin_w, dx2.sum(0), g_w_ih, g_w_hh, gi2.sum(0), gh2.sum(0), g_fc,
+                None, None, None, None, None, None)
+
+
 def observe_scan(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state):
     """Returns (h (B,T,D), z (B,T,L,K), post_logits (B,T,L,K), last WorldModelState)."""
-    return _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state)
+    if not e_part.is_cuda:
+        return _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state)
+    from . import _native as N
+    from .world_model import WorldModelState
+    eng = getattr(wm, "_observe_engine", None)
+    if eng is None:
+        eng = _ObserveEngine(wm)
+        object.__setattr__(wm, "_observe_engine", eng)
+    B, T = a_prev.shape
+    L, K = wm.num_latents, wm.classes_per_latent
+    g = wm.seq.gru
+    fc_w_h = wm.enc.fc[0].weight[:, wm.enc.conv_out_size:]
+    zidx0 = N.onehot_to_index(state.z.detach().contiguous().float())
+    h, z, post, zidx = ObserveScanFn.apply(eng, e_part, wm.seq.a_emb.weight, wm.seq.linear.weight, wm.seq.linear.bias,
+                                           g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh, fc_w_h, state.h.detach(), zidx0,
+                                           a_prev, c_prev, expo_reset, expo_z)
+    return h, z, post, WorldModelState(h=h[:, -1], z=z[:, -1])

@@ -1,0 +1,224 @@
+"""Training loop with the reference's entry point ``train(cfg, summary_writer=None)``
+(lib/trainer.py:16-342) on top of the MI355X hot path.
+
+Per environment step: one posterior step + actor draw (B = 1), store into the device-resident
+replay ring, then as many updates as the train-ratio credit allows.  One update
+(lib/trainer.py:162-247):
+
+    replay gather (HIP)  ->  world-model loss: hoisted convs, native observe scan, batched heads
+    -> backward, [data-parallel gradient all-reduce], clip, Adam
+    -> imagination block (native: actor / prior step x H, heads, critic value, lambda-return)
+    -> critic update (+ EMA copy)  ->  actor update
+
+Data parallel: launch with torchrun; every rank owns a replica, its own environment and replay ring
+(numpy seed offset by the rank) and a per-rank batch; gradients are averaged with one all-reduce per
+model before clipping, the actor's return percentiles are taken over the returns of all ranks, and
+only rank 0 logs and writes checkpoints.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as D
+from .actor import Actor
+from .config import Config
+from .critic import Critic
+from .imagine import imagine
+from .replay_buffer import ReplayBuffer
+from .utils import log_episode_video, log_wm_imagination_video, log_wm_reconstruction_video, make_env
+from .world_model import WorldModel, WorldModelState
+
+
+def _adam(params, lr, eps):
+    params = list(params)
+    return torch.optim.Adam(params, lr=lr, eps=eps, fused=params[0].is_cuda)
+
+
+class Learner:
+    """Models, optimisers and the update step; shared by ``train`` and the benchmark."""
+
+    def __init__(self, cfg: Config, obs_shape, act_size: int):
+        self.cfg = cfg
+        dev = cfg.device
+        self.world_model = WorldModel(obs_shape=obs_shape, action_size=act_size, num_latents=cfg.num_latents,
+                                      classes_per_latent=cfg.classes_per_latent, hidden_size=cfg.hidden_size,
+                                      base_cnn_channels=cfg.base_cnn_channels, mlp_hidden_units=cfg.mlp_hidden_units,
+                                      free_bits=cfg.free_bits, beta_pred=cfg.beta_pred, beta_dyn=cfg.beta_dyn,
+                                      beta_rep=cfg.beta_rep, unimix_eps=cfg.unimix_eps).to(dev).train()
+        state_size = cfg.hidden_size + cfg.num_latents * cfg.classes_per_latent
+        self.actor = Actor(state_size=state_size, action_size=act_size, mlp_hidden_units=cfg.mlp_hidden_units, mlp_layers=2,
+                           entropy_scale=cfg.actor_entropy_scale, ret_norm_limit=cfg.actor_ret_norm_limit,
+                           ret_norm_decay=cfg.actor_ret_norm_decay, unimix_eps=cfg.unimix_eps).to(dev).train()
+        self.critic = Critic(state_size=state_size, mlp_hidden_units=cfg.mlp_hidden_units, mlp_layers=2,
+                             num_buckets=cfg.critic_num_buckets, bucket_min=cfg.critic_bucket_min,
+                             bucket_max=cfg.critic_bucket_max, ema_decay=cfg.critic_ema_decay,
+                             ema_regularizer=cfg.critic_ema_regularizer).to(dev).train()
+        for m in (self.world_model, self.actor, self.critic):
+            D.broadcast_module(m)
+        self.actor.ret_scale.gather = D.gather_flat if D.world_size() > 1 else None
+        self.optim_world_model = _adam(self.world_model.parameters(), cfg.world_model_lr, cfg.world_model_adam_eps)
+        self.optim_actor = _adam(self.actor.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps)
+        self.optim_critic = _adam(self.critic.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps)
+        self.g_wm, self.g_actor, self.g_critic = D.FlatGrads(self.world_model), D.FlatGrads(self.actor), D.FlatGrads(self.critic)
+
+    def update(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        cfg = self.cfg
+        obs = batch.get("observations_f32")
+        if obs is None:
+            obs = batch["observations"].float() / 255.0
+        # ---- world model ----
+        wm_loss, wm_info = self.world_model.loss(obs, batch["actions"], batch["rewards"], batch["continues"])
+        self.g_wm.zero()
+        wm_loss.backward()
+        self.g_wm.sync()
+        nn.utils.clip_grad_norm_(self.world_model.parameters(), cfg.world_model_grad_clip)
+        self.optim_world_model.step()
+        # ---- imagination from the last posterior states, with the updated world model ----
+        start: WorldModelState = wm_info["state"]
+        im = imagine(self.world_model, self.actor, self.critic,
+                     WorldModelState(h=start.h.detach(), z=start.z.detach()), cfg.imagination_horizon, cfg.gamma, cfg.lam)
+        Hs = WorldModelState(h=im["h"], z=im["z"])
+        returns, values, actions = im["lam_returns"], im["values"], im["actions"]
+        # ---- critic ----
+        critic_loss = self.critic.loss(model_states=Hs, returns=returns)
+        self.g_critic.zero()
+        critic_loss.backward()
+        self.g_critic.sync()
+        nn.utils.clip_grad_norm_(self.critic.parameters(), cfg.actor_critic_grad_clip)
+        self.optim_critic.step()
+        self.critic.update_slow()
+        # ---- actor ----
+        actor_loss = self.actor.loss(model_states=Hs, actions=actions, returns=returns, values=values)
+        self.g_actor.zero()
+        actor_loss.backward()
+        self.g_actor.sync()
+        nn.utils.clip_grad_norm_(self.actor.parameters(), cfg.actor_critic_grad_clip)
+        self.optim_actor.step()
+        return {"world_model_loss": wm_loss.detach(), "actor_loss": actor_loss.detach(), "critic_loss": critic_loss.detach(),
+                "pred_loss": wm_info["pred_loss"].detach(), "dyn_loss": wm_info["dyn_loss"].detach(),
+                "rep_loss": wm_info["rep_loss"].detach(), "imagination": im}
+
+    def state_dicts(self):
+        return {"world_model": self.world_model.state_dict(), "actor": self.actor.state_dict(),
+                "critic": self.critic.state_dict(), "optim_world_model": self.optim_world_model.state_dict(),
+                "optim_actor": self.optim_actor.state_dict(), "optim_critic": self.optim_critic.state_dict()}
+
+
+def _log(writer, learner: Learner, out, step: int, ups: float):
+    cfg = learner.cfg
+    im = out["imagination"]
+    ret, V, R, C = im["lam_returns"], im["values"], im["rewards"], im["conts"]
+    logp = im["actor_logp"]
+    ent = -(logp.exp() * logp).sum(-1).mean().item()
+    scale = (learner.actor.ret_scale.p95 - learner.actor.ret_scale.p05).detach().clamp(min=cfg.actor_ret_norm_limit)
+    adv = (ret - V).reshape(-1)
+    s = writer.add_scalar
+    s("policy/ret_scale", scale.item(), step)
+    s("policy/adv_mean", adv.mean().item(), step)
+    s("policy/adv_std", adv.std(unbiased=False).item(), step)
+    s("policy/adv_mean_scaled", (adv / scale).mean().item(), step)
+    s("policy/adv_std_scaled", (adv / scale).std(unbiased=False).item(), step)
+    s("policy/imagination_entropy", ent, step)
+    writer.add_histogram("policy/imagination_probs", logp[:, -1].exp(), step)
+    s("value/mae_vs_returns", adv.abs().mean().item(), step)
+    s("value/bias_vs_returns", adv.mean().item(), step)
+    s("value/mean", V.mean().item(), step)
+    s("value/std", V.std(unbiased=False).item(), step)
+    s("value/lambda_ret_mean", ret.mean().item(), step)
+    s("value/lambda_ret_std", ret.std(unbiased=False).item(), step)
+    s("world_model/pred_loss", out["pred_loss"].item(), step)
+    s("world_model/dyn_loss", out["dyn_loss"].item(), step)
+    s("world_model/rep_loss", out["rep_loss"].item(), step)
+    s("world_model/rew_mean", R.mean().item(), step)
+    s("world_model/rew_std", R.std(unbiased=False).item(), step)
+    s("world_model/cont_mean", C.mean().item(), step)
+    s("train/world_model_loss", out["world_model_loss"].item(), step)
+    s("train/actor_loss", out["actor_loss"].item(), step)
+    s("train/critic_loss", out["critic_loss"].item(), step)
+    s("perf/updates_per_second", ups, step)
+    print(f"Update {step}, World Model Loss: {out['world_model_loss'].item():.3f}, Actor Loss: {out['actor_loss'].item():.3f}, "
+          f"Critic Loss: {out['critic_loss'].item():.3f}, Updates/sec: {ups:.3f}")
+
+
+def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
+    is_main = D.rank() == 0
+    env = env if env is not None else make_env(cfg.env_id)
+    act_space = env.action_space
+    assert hasattr(act_space, "n"), "Only discrete action space is supported."
+    obs_shape, act_size = env.observation_space.shape, int(act_space.n)
+    if is_main and verbose:
+        print(f"Observation shape: {obs_shape}, Action size: {act_size}")
+    learner = Learner(cfg, obs_shape, act_size)
+    wm, actor = learner.world_model, learner.actor
+    if is_main and verbose:
+        count = lambda m: sum(p.numel() for p in m.parameters())
+        print(f"World Model parameters: {count(wm):,}\nActor parameters: {count(actor):,}\n"
+              f"Critic parameters: {count(learner.critic):,}")
+    buffer = ReplayBuffer(capacity=cfg.replay_capacity, obs_shape=obs_shape, seq_len=cfg.batch_length, device=cfg.device)
+    if D.world_size() > 1:
+        np.random.seed((np.random.randint(0, 2 ** 31 - 1) + 7919 * D.rank()) % (2 ** 31 - 1))
+    writer = summary_writer if is_main else None
+
+    time_counter = time.time()
+    update_credit, credits_per_update = 0.0, cfg.batch_size * cfg.batch_length
+    updates_done = update_counter = policy_steps = 0
+    model_state = wm.init_state(1, cfg.device)
+    last_action = torch.zeros(1, dtype=torch.long, device=cfg.device)
+    last_cont = torch.ones(1, dtype=torch.float32, device=cfg.device)
+    current_obs = None
+    for _ in range(cfg.num_iterations):
+        if current_obs is None:
+            current_obs, _ = env.reset()
+        with torch.no_grad():
+            obs_t = torch.as_tensor(np.asarray(current_obs), dtype=torch.float32, device=cfg.device).unsqueeze(0) / 255.0
+            model_state, _ = wm.step(model_state, last_action, obs_t, last_cont)
+            action = actor(model_state).sample().item()
+        if updates_done == 0:
+            action = env.action_space.sample()
+        next_obs, reward, terminated, truncated, _ = env.step(action)
+        cont = not (terminated or truncated)
+        buffer.store(current_obs, action, float(reward), cont)
+        current_obs = next_obs
+        last_action.fill_(action)
+        last_cont.fill_(float(cont))
+        if not cont:
+            current_obs, _ = env.reset()
+            model_state = wm.init_state(1, cfg.device)
+            last_action.zero_()
+            last_cont.fill_(1.0)
+        policy_steps += 1
+        update_credit += cfg.train_ratio
+
+        while len(buffer) > cfg.batch_length and update_credit >= credits_per_update:
+            if is_main and verbose:
+                print(f"Update {updates_done}, total env steps {policy_steps}, buffer size {len(buffer)}, "
+                      f"update credit {update_credit:.1f}")
+            batch = buffer.sample(cfg.batch_size, want_f32=buffer.device.type == "cuda")
+            out = learner.update(batch)
+            if writer is not None and updates_done % cfg.log_interval == 0 and updates_done > 0:
+                elapsed = time.time() - time_counter
+                time_counter = time.time()
+                with torch.no_grad():
+                    _log(writer, learner, out, updates_done, update_counter / max(elapsed, 1e-9))
+                update_counter = 0
+            if updates_done % cfg.video_interval == 0 and updates_done > 0 and writer is not None:
+                wm.eval(); actor.eval()
+                log_episode_video(cfg, writer, env, wm, actor, updates_done)
+                log_wm_reconstruction_video(cfg, writer, env, wm, actor, updates_done)
+                log_wm_imagination_video(cfg, writer, env, wm, actor, updates_done)
+                wm.train(); actor.train()
+            if is_main and updates_done % cfg.save_interval == 0 and updates_done > 0 and cfg.checkpoint_dir is not None:
+                os.makedirs(cfg.checkpoint_dir, exist_ok=True)
+                torch.save(learner.state_dicts(), os.path.join(cfg.checkpoint_dir, "ckpt.pth"))
+                print(f"Saved model checkpoint to {cfg.checkpoint_dir}")
+            update_credit -= credits_per_update
+            updates_done += 1
+            update_counter += 1
+    env.close()
+    return learner

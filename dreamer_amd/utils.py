@@ -73,7 +73,8 @@ class SyntheticPixelEnv:
             self._rng = np.random.default_rng(seed)
             self.action_space._rng = self._rng
         self._t = 0
-        self._pos = self._rng.integers(8, self._size - 8, size=2)
+        m = min(8, self._size // 4)
+        self._pos = self._rng.integers(m, self._size - m, size=2)
         return self._frame(), {}
 
     def step(self, action: int):

@@ -202,6 +202,55 @@ int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io
 /* Destroys the recorded graphs (at most 16 are kept, oldest evicted first). */
 int drm_graph_cache_clear(void);
 
+/* ---- observe (posterior) recurrence: the time loop of lib/world_model.py:563-589 ---------------
+ * For t = 0..T-1 and B replayed sequences (c = c_prev[b,t] in {0,1}):
+ *     z_in  = c ? z_{t-1} : one_hot(argmax softmax(1/K - log expo_reset[t,b]))   (lib/world_model.py:57-61)
+ *     h_in  = c * h_{t-1};   x = lin_b + sum_l lin_w[:, l*K + z_in[l]] + c * lin_w[:, L*K:] a_emb[a_prev[b,t]]
+ *     h_t   = GRUCell(x, h_in)                                                       (lib/world_model.py:64-71)
+ *     post  = e_part[b,t] + fc_w_h h_t      (e_part = enc.fc over the hoisted conv features, bias included)
+ *     z_t   = straight-through Gumbel-argmax of log_unimix(post) with expo_z[t,b]    (lib/world_model.py:459-461)
+ * Everything the backward pass needs is written out.  The decoder, prior MLP, heads and losses do
+ * not depend on the recurrence order and are evaluated by the caller over all B*T states. */
+typedef struct drm_observe_weights {
+    drm_dims dims;           /* D, L, K, A, E, unimix_eps used */
+    const float* a_emb;      /* (A,E) */
+    const float* lin_w;      /* seq.linear.weight (D, L*K+E) */
+    const float* lin_b;
+    const float* gru_w_ih; const float* gru_w_hh; const float* gru_b_ih; const float* gru_b_hh;
+    const float* fc_w_h;     /* enc.fc.0.weight[:, conv_out:]  (L*K, D) with row stride ld_fc */
+    int64_t ld_fc;
+    const float* pack;       /* written by drm_pack_observe */
+    size_t pack_bytes;
+} drm_observe_weights;
+
+size_t drm_pack_observe_bytes(const drm_dims* dims);
+int drm_pack_observe(const drm_observe_weights* w, float* pack_out, size_t pack_bytes, drm_stream_t stream);
+
+typedef struct drm_observe_io {
+    int32_t B, T;
+    const float* h0;          /* (B,D) */
+    const uint8_t* zidx0;     /* (B,L) */
+    const int64_t* a_prev;    /* (B,T) */
+    const float* c_prev;      /* (B,T) values 0 or 1 */
+    const float* expo_reset;  /* (T,B,L,K) */
+    const float* expo_z;      /* (T,B,L,K) */
+    const float* e_part;      /* (B,T,L*K) */
+    float* h_out;             /* (B,T,D) */
+    uint8_t* zidx_out;        /* (B,T,L) sampled z_t */
+    uint8_t* zidx_in_out;     /* (B,T,L) z fed into step t after the reset */
+    float* z_out;             /* (B,T,L,K) dense one-hot of z_t */
+    float* post_out;          /* (B,T,L,K) posterior logits */
+    float* y_out;             /* (B,T,L,K) soft sample probabilities */
+    float* gates_out;         /* (B,T,4D): r, u, n, gh_n */
+    float* x_out;             /* (B,T,D) GRU input */
+    float* h_in_out;          /* (B,T,D) c * h_{t-1} */
+    void* workspace; size_t workspace_bytes;
+    int32_t use_graph;
+} drm_observe_io;
+
+size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, int32_t T);
+int drm_observe_forward_f32(const drm_observe_weights* w, const drm_observe_io* io, drm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

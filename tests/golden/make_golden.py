@@ -226,7 +226,7 @@ def golden_observe(tag, out_dir, salt):
                h_last=info["state"].h.detach().numpy())
     gn = {}
     for k, p in wm.named_parameters():
-        gn[k] = float(p.grad.norm()) if p.grad is not None else -1.0
+        gn[k] = float(p.grad.double().norm()) if p.grad is not None else -1.0  # fp64: an fp32 sum over 1e7 squares drifts
     out["grad_names"] = np.array(list(gn.keys()))
     out["grad_norms"] = np.array(list(gn.values()), dtype=np.float64)
     for k in ("seq.gru.weight_hh", "seq.linear.weight", "enc.fc.0.weight", "dyn.head.bias", "seq.a_emb.weight"):

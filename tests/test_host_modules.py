@@ -56,7 +56,7 @@ def test_world_model_loss_matches_reference(tag):
         if ref < 0:
             assert grad is None, name
         else:
-            assert abs(float(grad.norm()) - ref) <= 5e-5 * max(ref, 1e-3), name
+            assert abs(float(grad.double().norm()) - ref) <= 5e-5 * max(ref, 1e-3), name
     for key in g.files:
         if key.startswith("grad:"):
             assert rel_err(params[key[5:]].grad.reshape(-1)[:256], g[key]) < 1e-4, key

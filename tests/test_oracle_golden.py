@@ -114,7 +114,7 @@ def test_observe_loss_and_grads(tag):
         if ref < 0:
             assert grad is None or float(grad.abs().max()) == 0.0, name  # seq.norm.* receive no gradient
         else:
-            assert abs(float(grad.norm()) - ref) <= 5e-5 * max(ref, 1e-3), name
+            assert abs(float(grad.double().norm()) - ref) <= 5e-5 * max(ref, 1e-3), name
     for key in g.files:
         if key.startswith("grad:"):
             got = w[key[5:]].grad.reshape(-1)[:256]
