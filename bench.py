@@ -105,6 +105,7 @@ def measure_train(device, world, rank, steps, warmup, fence):
     from dreamer_amd.trainer import Learner
     cfg = Config(device=device)
     torch.manual_seed(0)
+    torch.backends.cudnn.benchmark = True   # as the reference's main.py:11 sets it (MIOpen picks its conv kernels by search)
     learner = Learner(cfg, (3, 64, 64), 6)
     with torch.no_grad():
         for head in (learner.world_model.rew.head, learner.world_model.cont.head, learner.actor.head, learner.critic.head):
@@ -225,7 +226,7 @@ def main():
 
     train = None
     if args.train_steps > 0:
-        train = measure_train(device, world, rank, args.train_steps, 3, fence)
+        train = measure_train(device, world, rank, args.train_steps, 6, fence)
 
     if rank == 0:
         value = world * B * H * args.steps / elapsed

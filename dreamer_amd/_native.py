@@ -83,6 +83,12 @@ class drm_observe_io(C.Structure):
                 ("use_graph", C.c_int32)]
 
 
+class drm_observe_bwd_io(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "c_prev", "y", "wmix", "psoft", "gates", "h_in", "g_h", "g_z", "g_post", "fc_w_hT", "gru_w_ihT", "gru_w_hhT",
+        "lin_zT", "d_gi", "d_gh", "d_x", "d_post", "workspace")] + [("workspace_bytes", C.c_size_t)]
+
+
 # name -> (restype, argtypes); must list every symbol include/dreamer_amd.h declares
 SIGNATURES = {
     "drm_version": (C.c_int, []),
@@ -107,6 +113,8 @@ SIGNATURES = {
     "drm_pack_observe": (C.c_int, [C.POINTER(drm_observe_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_observe_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
     "drm_observe_forward_f32": (C.c_int, [C.POINTER(drm_observe_weights), C.POINTER(drm_observe_io), C.c_void_p]),
+    "drm_observe_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32]),
+    "drm_observe_backward_f32": (C.c_int, [C.POINTER(drm_dims), C.POINTER(drm_observe_bwd_io), C.c_void_p]),
 }
 
 

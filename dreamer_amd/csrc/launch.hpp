@@ -12,11 +12,14 @@ struct ProblemSpec {
     const float* X; int64_t ldx; const float* ln_g; const float* ln_b;
     const float* W; int64_t ldw; const float* bias; const float* tab; int64_t ldt;
     float* Y; int64_t ldy; int N, K;
+    const float* add = nullptr; int64_t ldadd = 0;          // Y += add[m][n]
+    const float* rowscale = nullptr; int64_t ldrs = 0;      // Y *= rowscale[m]
 };
 
 static inline int check_problem(const ProblemSpec& s) {
     DRM_REQUIRE(s.X && s.W && s.Y, DRM_EINVAL, "null pointer in linear problem");
-    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0 && s.K <= 512, DRM_ENOTSUP, "K=%d must be a multiple of 32 in [32, 512]", s.K);
+    DRM_REQUIRE(s.K >= 32 && s.K % 32 == 0 && s.K <= 4096, DRM_ENOTSUP, "K=%d must be a multiple of 32 in [32, 4096]", s.K);
+    DRM_REQUIRE(!s.ln_g || s.K <= 512, DRM_ENOTSUP, "LayerNorm prologue needs K <= 512 (got %d)", s.K);
     DRM_REQUIRE(s.N >= 1, DRM_EINVAL, "N=%d", s.N);
     DRM_REQUIRE(aligned16(s.X) && aligned16(s.W) && s.ldx % 4 == 0 && s.ldw % 4 == 0, DRM_EINVAL,
                 "X/W must be 16-byte aligned with row strides a multiple of 4 floats");
@@ -36,6 +39,7 @@ static inline int launch_store(const ProblemSpec* specs, int np, int M, const ui
         p.X = specs[i].X; p.ldx = specs[i].ldx; p.ln_g = specs[i].ln_g; p.ln_b = specs[i].ln_b;
         p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.tab = specs[i].tab; p.ldt = specs[i].ldt;
         p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.tile_begin = tiles;
+        p.add = specs[i].add; p.ldadd = specs[i].ldadd; p.rowscale = specs[i].rowscale; p.ldrs = specs[i].ldrs;
         tiles += (specs[i].N + 15) / 16;
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
@@ -51,9 +55,9 @@ static inline int launch_store(const ProblemSpec* specs, int np, int M, const ui
     ProfScope prof(PC_LINEAR, stream, fl, by);
     const dim3 grid(tiles, (M + 15) / 16), block(256);
     switch (chunks_for(kmax)) {
-        case 1: k_linear16<1, EPI_STORE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
-        case 2: k_linear16<1, EPI_STORE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
-        default: k_linear16<1, EPI_STORE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}); break;
+        case 1: k_linear16<1, EPI_STORE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, BwdEpilogue{}); break;
+        case 2: k_linear16<1, EPI_STORE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, BwdEpilogue{}); break;
+        default: k_linear16<1, EPI_STORE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, BwdEpilogue{}); break;
     }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -70,9 +74,9 @@ static inline int launch_gru(const ProblemSpec& spec, int M, const GruEpilogue& 
                    4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + 5.0 * M * G.D + M * G.D));
     const dim3 grid(G.D / 16, (M + 15) / 16), block(256);
     switch (chunks_for(spec.K)) {
-        case 1: k_linear16<3, EPI_GRU, 1><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
-        case 2: k_linear16<3, EPI_GRU, 2><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
-        default: k_linear16<3, EPI_GRU, 4><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}); break;
+        case 1: k_linear16<3, EPI_GRU, 1><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}, BwdEpilogue{}); break;
+        case 2: k_linear16<3, EPI_GRU, 2><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}, BwdEpilogue{}); break;
+        default: k_linear16<3, EPI_GRU, 4><<<grid, block, 0, stream>>>(L, G, SampleEpilogue{}, BwdEpilogue{}); break;
     }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -106,13 +110,48 @@ static inline int launch_sample(const ProblemSpec& spec, int M, int latents, con
                    4.0 * ((double)M * spec.K + (double)spec.N * spec.K + spec.N + (double)M * spec.N) + (double)M * latents + xby);
     const dim3 grid(tiles, (M + 15) / 16), block(256);
     switch (chunks_for(kmax)) {
-        case 1: k_linear16<2, EPI_SAMPLE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
-        case 2: k_linear16<2, EPI_SAMPLE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
-        default: k_linear16<2, EPI_SAMPLE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S); break;
+        case 1: k_linear16<2, EPI_SAMPLE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S, BwdEpilogue{}); break;
+        case 2: k_linear16<2, EPI_SAMPLE, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S, BwdEpilogue{}); break;
+        default: k_linear16<2, EPI_SAMPLE, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, S, BwdEpilogue{}); break;
     }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
 
+
+// d(h) GEMM of the reverse observe step with the GRU cell's elementwise backward as its epilogue
+static inline int launch_grubwd(const ProblemSpec& spec, int M, const BwdEpilogue& E, hipStream_t stream) {
+    if (int rc = check_problem(spec)) return rc;
+    DRM_REQUIRE(spec.N == E.D && E.D % 16 == 0, DRM_ENOTSUP, "GRU width %d", E.D);
+    LinLaunch L{};
+    LinProblem& p = L.p[0];
+    p.X = spec.X; p.ldx = spec.ldx; p.W = spec.W; p.ldw = spec.ldw; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
+    L.np = 1; L.M = M;
+    ProfScope prof(PC_GRU, stream, 2.0 * M * spec.N * spec.K + 30.0 * M * E.D,
+                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + 14.0 * M * E.D));
+    k_linear16<1, EPI_GRUBWD, 4><<<dim3(E.D / 16, (M + 15) / 16), dim3(256), 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, E);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+// d(z) GEMM of the reverse observe step with the straight-through sample backward as its epilogue
+static inline int launch_stbwd(const ProblemSpec& spec, int M, int latents, const BwdEpilogue& E, hipStream_t stream) {
+    if (int rc = check_problem(spec)) return rc;
+    DRM_REQUIRE(spec.N == latents * 32, DRM_EINVAL, "N must be 32*latents");
+    LinLaunch L{};
+    LinProblem& p = L.p[0];
+    p.X = spec.X; p.ldx = spec.ldx; p.W = spec.W; p.ldw = spec.ldw; p.N = spec.N; p.K = spec.K; p.tile_begin = 0;
+    L.np = 1; L.M = M;
+    ProfScope prof(PC_DYN_SAMPLE, stream, 2.0 * M * spec.N * spec.K + 12.0 * M * spec.N,
+                   4.0 * ((double)M * spec.K + (double)spec.N * spec.K + 6.0 * M * spec.N));
+    const dim3 grid(latents, (M + 15) / 16), block(256);
+    switch (chunks_for(spec.K)) {
+        case 1: k_linear16<2, EPI_STBWD, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, E); break;
+        case 2: k_linear16<2, EPI_STBWD, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, E); break;
+        default: k_linear16<2, EPI_STBWD, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, E); break;
+    }
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
 
 }  // namespace drm

@@ -37,6 +37,9 @@ struct LinProblem {
     float* Y; int64_t ldy;
     int N, K;
     int tile_begin;                            // first blockIdx.x of this problem
+    // store epilogue extras: Y = (acc + bias + table rows + add[m][n]) * rowscale[m]
+    const float* add; int64_t ldadd;
+    const float* rowscale; int64_t ldrs;
 };
 
 struct LinLaunch {
@@ -70,7 +73,26 @@ struct SampleEpilogue {    // one latent (32 classes) per workgroup
     float log1m_eps, log_eps_over_k;
 };
 
-enum { EPI_STORE = 0, EPI_GRU = 1, EPI_SAMPLE = 2 };
+// Epilogues of the reverse-time (backward) observe recurrence.
+struct BwdEpilogue {
+    // EPI_GRUBWD (NT = 1, columns = GRU units j): dh = acc + g_h + dh_next, then the GRU cell's
+    // elementwise backward -> d(gi), d(gh) for the three gates and dh * u
+    const float* g_h; int64_t ldgh;        // upstream gradient wrt h_t, (M, D)
+    const float* dh_next; int64_t lddn;    // gradient arriving from step t+1, (M, D)
+    const float* gates; int64_t ldg;       // (M, 4D): r, u, n, gh_n saved by the forward pass
+    const float* h_in; int64_t ldhi;       // (M, D)
+    float* dgi; float* dgh; int64_t lddg;  // (M, 3D) each
+    float* dhu; int64_t lddhu;             // (M, D)
+    int D;
+    // EPI_STBWD (NT = 2, one latent per workgroup): dz = acc * rowscale + g_z, then the
+    // straight-through sample / unimix / log-softmax backward -> d(posterior logits)
+    const float* rowscale; int64_t ldrs;   // (M) or nullptr (acc ignored when skip_acc)
+    const float* g_z; const float* y; const float* wmix; const float* psoft; const float* g_post; int64_t ldl;  // (M, L*32)
+    float* dpost; int64_t lddp;            // (M, L*32)
+    int skip_acc;
+};
+
+enum { EPI_STORE = 0, EPI_GRU = 1, EPI_SAMPLE = 2, EPI_GRUBWD = 3, EPI_STBWD = 4 };
 
 __device__ __forceinline__ const LinProblem& pick_problem(const LinLaunch& L, int bx, int& tile) {
     int i = L.np - 1;
@@ -86,7 +108,8 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
 }
 
 template <int NT, int EPI, int CH>
-__global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEpilogue G, const SampleEpilogue S) {
+__global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEpilogue G, const SampleEpilogue S,
+                                                   const BwdEpilogue Bw) {
     __shared__ __attribute__((aligned(16))) float s_part[4][NT][16][16];
     __shared__ float s_red[2][4][16];
     __shared__ uint8_t s_zi[16][MAX_LATENTS];
@@ -108,87 +131,87 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
         else nbase[t] = (tile * NT + t) * 16;
     }
 
-    // ---- issue every load up front ----
     const float* xrow = P.X + (int64_t)min(m0 + r, L.M - 1) * P.ldx + q * 8;
     const float* wrow[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wrow[t] = P.W + (int64_t)min(nbase[t] + r, P.N - 1) * P.ldw + q * 8;
-
-    float a[CH][8], b[CH][NT][8], g[CH][8], e[CH][8];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int kc = (c * 4 + wave) * 32;
-        if (kc < K) {
-            load8(xrow + kc, a[c]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) load8(wrow[t] + kc, b[c][t]);
-            if (ln) { load8(P.ln_g + kc + q * 8, g[c]); load8(P.ln_b + kc + q * 8, e[c]); }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) a[c][s] = 0.f;
-        }
-    }
     if (EPI == EPI_STORE && P.tab != nullptr) {
         for (int i = threadIdx.x; i < 16 * L.latents; i += 256) {
             const int row = i / L.latents, l = i - row * L.latents;
             s_zi[row][l] = L.zidx[(int64_t)min(m0 + row, L.M - 1) * L.ldz + l];
         }
     }
-
-#ifdef DRM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP();
-#endif
-    // ---- LayerNorm + SiLU of the producing layer, from the fragments in registers ----
-    if (ln) {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) s += a[c][i];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (q == 0) s_red[0][wave][r] = s;
-        __syncthreads();
-        const float mean = ((s_red[0][0][r] + s_red[0][1][r]) + (s_red[0][2][r] + s_red[0][3][r])) / (float)K;
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if ((c * 4 + wave) * 32 < K) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { const float d = a[c][i] - mean; v += d * d; }
-            }
-        }
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (q == 0) s_red[1][wave][r] = v;
-        __syncthreads();
-        const float var = ((s_red[1][0][r] + s_red[1][1][r]) + (s_red[1][2][r] + s_red[1][3][r])) / (float)K;
-        const float rstd = 1.0f / sqrtf(var + LN_EPS);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if ((c * 4 + wave) * 32 < K) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) a[c][i] = silu_f((a[c][i] - mean) * rstd * g[c][i] + e[c][i]);
-            }
-        }
-    }
-
-#ifdef DRM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    STAMP();
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // K is walked in passes of CH chunks per wave; inside a pass every load is issued before the first
+    // use of any of them (the kernel is latency-bound).  LayerNorm needs the whole row: one pass only.
+    for (int k0 = 0; k0 < K; k0 += CH * 128) {
+        float a[CH][8], b[CH][NT][8], g[CH][8], e[CH][8];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        if ((c * 4 + wave) * 32 < K) {
+        for (int c = 0; c < CH; ++c) {
+            const int kc = k0 + (c * 4 + wave) * 32;
+            if (kc < K) {
+                load8(xrow + kc, a[c]);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+                for (int t = 0; t < NT; ++t) load8(wrow[t] + kc, b[c][t]);
+                if (ln) { load8(P.ln_g + kc + q * 8, g[c]); load8(P.ln_b + kc + q * 8, e[c]); }
+            } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s], b[c][t][s], acc[t], 0, 0, 0);
+                for (int s = 0; s < 8; ++s) a[c][s] = 0.f;
+            }
+        }
+#ifdef DRM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP();
+#endif
+        // ---- LayerNorm + SiLU of the producing layer, from the fragments in registers ----
+        if (ln) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += a[c][i];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (q == 0) s_red[0][wave][r] = s;
+            __syncthreads();
+            const float mean = ((s_red[0][0][r] + s_red[0][1][r]) + (s_red[0][2][r] + s_red[0][3][r])) / (float)K;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float d = a[c][i] - mean; v += d * d; }
+                }
+            }
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) s_red[1][wave][r] = v;
+            __syncthreads();
+            const float var = ((s_red[1][0][r] + s_red[1][1][r]) + (s_red[1][2][r] + s_red[1][3][r])) / (float)K;
+            const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a[c][i] = silu_f((a[c][i] - mean) * rstd * g[c][i] + e[c][i]);
+                }
+            }
+        }
+#ifdef DRM_STAMPS
+        STAMP();
+#endif
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (k0 + (c * 4 + wave) * 32 < K) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s], b[c][t][s], acc[t], 0, 0, 0);
+            }
         }
     }
 
@@ -228,8 +251,42 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
                 }
                 for (; l < L.latents; ++l) y += tb[(int64_t)(l * L.classes + s_zi[row][l]) * P.ldt];
             }
+            if (P.add != nullptr) y += P.add[(int64_t)m * P.ldadd + n];
+            if (P.rowscale != nullptr) y *= P.rowscale[(int64_t)m * P.ldrs];
             P.Y[(int64_t)m * P.ldy + n] = y;
         }
+    } else if (EPI == EPI_GRUBWD) {
+        if (m >= L.M) return;
+        const int j = tile * 16 + col;
+        if (j >= Bw.D) return;
+        const int D = Bw.D;
+        const float* gt = Bw.gates + (int64_t)m * Bw.ldg;
+        const float rr = gt[j], uu = gt[D + j], nn = gt[2 * D + j], ghn = gt[3 * D + j];
+        const float hin = Bw.h_in[(int64_t)m * Bw.ldhi + j];
+        const float dh = v[0] + Bw.g_h[(int64_t)m * Bw.ldgh + j] + Bw.dh_next[(int64_t)m * Bw.lddn + j];
+        const float dn_pre = dh * (1.0f - uu) * (1.0f - nn * nn);
+        const float du_pre = dh * (hin - nn) * uu * (1.0f - uu);
+        const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
+        float* gi = Bw.dgi + (int64_t)m * Bw.lddg;
+        float* gh = Bw.dgh + (int64_t)m * Bw.lddg;
+        gi[j] = dr_pre; gi[D + j] = du_pre; gi[2 * D + j] = dn_pre;
+        gh[j] = dr_pre; gh[D + j] = du_pre; gh[2 * D + j] = dn_pre * rr;
+        Bw.dhu[(int64_t)m * Bw.lddhu + j] = dh * uu;
+    } else if (EPI == EPI_STBWD) {   // NT == 2: this workgroup holds the 32 classes of latent `tile` for 16 rows
+        const int lat = tile;
+        const int mm = min(m, L.M - 1);
+        const int64_t o0 = (int64_t)mm * Bw.ldl + lat * 32 + col, o1 = o0 + 16;
+        const float rs = Bw.rowscale ? Bw.rowscale[(int64_t)mm * Bw.ldrs] : 1.0f;
+        const float dz0 = (Bw.skip_acc ? 0.f : v[0] * rs) + Bw.g_z[o0];
+        const float dz1 = (Bw.skip_acc ? 0.f : v[1] * rs) + Bw.g_z[o1];
+        const float y0 = Bw.y[o0], y1 = Bw.y[o1];
+        const float s1 = group_sum<16>(y0 * dz0 + y1 * dz1);
+        const float dl0 = y0 * (dz0 - s1) * Bw.wmix[o0], dl1 = y1 * (dz1 - s1) * Bw.wmix[o1];
+        const float s2 = group_sum<16>(dl0 + dl1);
+        if (m >= L.M) return;
+        float* dp = Bw.dpost + (int64_t)m * Bw.lddp + lat * 32;
+        dp[col] = dl0 - Bw.psoft[o0] * s2 + Bw.g_post[o0];
+        dp[16 + col] = dl1 - Bw.psoft[o1] * s2 + Bw.g_post[o1];
     } else if (EPI == EPI_GRU) {
         if (m >= L.M) return;
         const int j = tile * 16 + col;
@@ -304,7 +361,7 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
     }
 }
 
-// CH (chunks of 32 per wave) for a K: 1, 2 or 4; K > 512 is not built
+// CH (chunks of 32 per wave and pass) for a K: 1, 2 or 4; K > 512 takes several passes of 4
 inline int chunks_for(int K) { return K <= 128 ? 1 : (K <= 256 ? 2 : 4); }
 
 }  // namespace drm

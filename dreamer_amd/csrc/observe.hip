@@ -265,3 +265,63 @@ extern "C" int drm_observe_forward_f32(const drm_observe_weights* w, const drm_o
     DRM_HIP(hipGraphLaunch(exec, s));
     return DRM_OK;
 }
+
+extern "C" size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t B) {
+    if (!dims || check_observe_dims(*dims) != DRM_OK || B < 1) return 0;
+    return (size_t)B * 3 * dims->D * sizeof(float);   // dh*u, and two alternating dh_next buffers
+}
+
+extern "C" int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io, drm_stream_t stream) {
+    DRM_REQUIRE(dims && io, DRM_EINVAL, "null pointer");
+    if (int rc = check_observe_dims(*dims)) return rc;
+    const drm_dims& d = *dims;
+    const int B = io->B, T = io->T, D = d.D, L = d.L, LK = d.L * d.K;
+    DRM_REQUIRE(B >= 1 && T >= 1, DRM_EINVAL, "B=%d T=%d", B, T);
+    DRM_REQUIRE(io->c_prev && io->y && io->wmix && io->psoft && io->gates && io->h_in && io->g_h && io->g_z && io->g_post &&
+                    io->fc_w_hT && io->gru_w_ihT && io->gru_w_hhT && io->lin_zT && io->d_gi && io->d_gh && io->d_x && io->d_post,
+                DRM_EINVAL, "null io pointer");
+    DRM_REQUIRE(io->workspace && io->workspace_bytes >= (size_t)B * 3 * D * sizeof(float) && aligned16(io->workspace),
+                DRM_EINVAL, "workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* dhu = (float*)io->workspace;
+    float* dhn[2] = {dhu + (size_t)B * D, dhu + (size_t)2 * B * D};
+    const int64_t TD = (int64_t)T * D, T3D = (int64_t)T * 3 * D, T4D = (int64_t)T * 4 * D, TLK = (int64_t)T * LK;
+    DRM_HIP(hipMemsetAsync(dhn[0], 0, (size_t)B * D * sizeof(float), s));
+    auto stbwd = [&](int t, const float* dx_next, bool skip) -> int {
+        // d(post)[t] from dz = (d(x)[t+1] @ lin_z) * c[t+1] + g_z[t]
+        BwdEpilogue E{};
+        E.rowscale = skip ? nullptr : io->c_prev + (t + 1); E.ldrs = T;
+        E.g_z = io->g_z + (size_t)t * LK; E.y = io->y + (size_t)t * LK; E.wmix = io->wmix + (size_t)t * LK;
+        E.psoft = io->psoft + (size_t)t * LK; E.g_post = io->g_post + (size_t)t * LK; E.ldl = TLK;
+        E.dpost = io->d_post + (size_t)t * LK; E.lddp = TLK;
+        E.skip_acc = skip ? 1 : 0;
+        ProblemSpec p{skip ? io->h_in : dx_next, TD, nullptr, nullptr, io->lin_zT, D, nullptr, nullptr, 0, dhu, 0, LK, D};
+        return launch_stbwd(p, B, L, E, s);
+    };
+    if (int rc = stbwd(T - 1, nullptr, true)) return rc;
+    for (int t = T - 1; t >= 0; --t) {
+        const int cur = (T - 1 - t) & 1;
+        {   // dh = d(post)[t] @ fc_w_h + g_h[t] + dh_next; GRU cell backward
+            ProblemSpec p{io->d_post + (size_t)t * LK, TLK, nullptr, nullptr, io->fc_w_hT, LK, nullptr, nullptr, 0, dhu, D, D, LK};
+            BwdEpilogue E{};
+            E.g_h = io->g_h + (size_t)t * D; E.ldgh = TD; E.dh_next = dhn[cur]; E.lddn = D;
+            E.gates = io->gates + (size_t)t * 4 * D; E.ldg = T4D; E.h_in = io->h_in + (size_t)t * D; E.ldhi = TD;
+            E.dgi = io->d_gi + (size_t)t * 3 * D; E.dgh = io->d_gh + (size_t)t * 3 * D; E.lddg = T3D;
+            E.dhu = dhu; E.lddhu = D; E.D = D;
+            if (int rc = launch_grubwd(p, B, E, s)) return rc;
+        }
+        {   // d(x)[t] = d(gi) @ W_ih;  dh_next = (dh*u + d(gh) @ W_hh) * c[t]
+            ProblemSpec p[2] = {
+                {io->d_gi + (size_t)t * 3 * D, T3D, nullptr, nullptr, io->gru_w_ihT, 3 * D, nullptr, nullptr, 0,
+                 io->d_x + (size_t)t * D, TD, D, 3 * D},
+                {io->d_gh + (size_t)t * 3 * D, T3D, nullptr, nullptr, io->gru_w_hhT, 3 * D, nullptr, nullptr, 0, dhn[cur ^ 1], D, D,
+                 3 * D}};
+            p[1].add = dhu; p[1].ldadd = D; p[1].rowscale = io->c_prev + t; p[1].ldrs = T;
+            if (int rc = launch_store(p, 2, B, nullptr, 0, 0, 0, s)) return rc;
+        }
+        if (t > 0) {
+            if (int rc = stbwd(t - 1, io->d_x + (size_t)t * D, false)) return rc;
+        }
+    }
+    return DRM_OK;
+}

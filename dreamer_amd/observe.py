@@ -102,53 +102,44 @@ class ObserveScanFn(torch.autograd.Function):
         N.check(N.lib().drm_observe_forward_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_observe_forward_f32")
         ctx.save_for_backward(a_emb, lin_w, w_ih, w_hh, fc_w_h, a_prev, c_prev, h, zidx_in, post, y, gates, x, h_in)
         ctx.eps = float(d.unimix_eps)
+        ctx.eng = eng
         ctx.mark_non_differentiable(zidx)
         return h, z, post, zidx
 
     @staticmethod
     def backward(ctx, g_h, g_z, g_post, _g_zidx):
         a_emb, lin_w, w_ih, w_hh, fc_w_h, a_prev, c_prev, h, zidx_in, post, y, gates, x, h_in = ctx.saved_tensors
+        eng = ctx.eng
+        N = eng.N
         B, T, D = h.shape
         L, K = post.shape[2], post.shape[3]
         LK = L * K
         eps = ctx.eps
+        dev = h.device
         log1m, floor = math.log1p(-eps), math.log(eps) - math.log(K)
-        g_h = torch.zeros_like(h) if g_h is None else g_h
-        g_z = torch.zeros_like(post) if g_z is None else g_z
-        g_post = torch.zeros_like(post) if g_post is None else g_post
-        lin_wz, lin_wa = lin_w[:, :LK], lin_w[:, LK:]
-        # unimix / log-softmax pieces for all steps at once (elementwise, time-parallel)
+        g_h = torch.zeros_like(h) if g_h is None else g_h.contiguous()
+        g_z = torch.zeros_like(post) if g_z is None else g_z.contiguous()
+        g_post = torch.zeros_like(post) if g_post is None else g_post.contiguous()
+        # time-parallel pieces of the unimix / log-softmax backward
         ls = F.log_softmax(post, dim=-1)
-        lp = torch.logaddexp(ls + log1m, ls.new_tensor(floor))
-        w_mix = torch.exp(ls + log1m - lp)
+        w_mix = torch.exp(ls + log1m - torch.logaddexp(ls + log1m, ls.new_tensor(floor)))
         p_soft = ls.exp()
-        d_post = torch.empty_like(post)
-        d_gi = torch.empty(B, T, 3 * D, device=h.device, dtype=h.dtype)
+        fcT, ihT, hhT = fc_w_h.t().contiguous(), w_ih.t().contiguous(), w_hh.t().contiguous()
+        d_gi = torch.empty(B, T, 3 * D, device=dev, dtype=h.dtype)
         d_gh = torch.empty_like(d_gi)
         d_x = torch.empty_like(x)
-        dh_next = torch.zeros(B, D, device=h.device, dtype=h.dtype)
-        dz_next = torch.zeros(B, L, K, device=h.device, dtype=h.dtype)
-        for t in range(T - 1, -1, -1):
-            dz = g_z[:, t] + dz_next
-            yt = y[:, t]
-            dscore = yt * (dz - (yt * dz).sum(-1, keepdim=True))
-            dls = dscore * w_mix[:, t]
-            dp = dls - p_soft[:, t] * dls.sum(-1, keepdim=True) + g_post[:, t]
-            d_post[:, t] = dp
-            dh = g_h[:, t] + dh_next + dp.reshape(B, LK) @ fc_w_h
-            r, u, n, ghn = gates[:, t].split(D, dim=-1)
-            hin = h_in[:, t]
-            dn_pre = dh * (1.0 - u) * (1.0 - n * n)
-            du_pre = dh * (hin - n) * u * (1.0 - u)
-            dr_pre = dn_pre * ghn * r * (1.0 - r)
-            gi = torch.cat([dr_pre, du_pre, dn_pre], dim=-1)
-            gh = torch.cat([dr_pre, du_pre, dn_pre * r], dim=-1)
-            d_gi[:, t], d_gh[:, t] = gi, gh
-            dx = gi @ w_ih
-            d_x[:, t] = dx
-            c = c_prev[:, t:t + 1]
-            dh_next = (dh * u + gh @ w_hh) * c
-            dz_next = (dx @ lin_wz).view(B, L, K) * c.view(B, 1, 1)
+        d_post = torch.empty_like(post)
+        ws_bytes = N.lib().drm_observe_bwd_workspace_bytes(C.byref(eng.dims), B)
+        ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
+        io = N.drm_observe_bwd_io()
+        io.B, io.T = B, T
+        io.c_prev, io.y, io.wmix, io.psoft = c_prev.data_ptr(), y.data_ptr(), w_mix.data_ptr(), p_soft.data_ptr()
+        io.gates, io.h_in = gates.data_ptr(), h_in.data_ptr()
+        io.g_h, io.g_z, io.g_post = g_h.data_ptr(), g_z.data_ptr(), g_post.data_ptr()
+        io.fc_w_hT, io.gru_w_ihT, io.gru_w_hhT, io.lin_zT = fcT.data_ptr(), ihT.data_ptr(), hhT.data_ptr(), eng.pack.data_ptr()
+        io.d_gi, io.d_gh, io.d_x, io.d_post = d_gi.data_ptr(), d_gh.data_ptr(), d_x.data_ptr(), d_post.data_ptr()
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        N.check(N.lib().drm_observe_backward_f32(C.byref(eng.dims), C.byref(io), N.stream_ptr(dev)), "drm_observe_backward_f32")
         # weight gradients: one batched product each over all B*T rows
         gi2, gh2, dx2 = d_gi.reshape(B * T, -1), d_gh.reshape(B * T, -1), d_x.reshape(B * T, D)
         c2 = c_prev.reshape(B * T, 1)
@@ -158,7 +149,7 @@ class ObserveScanFn(torch.autograd.Function):
         g_w_ih = gi2.t() @ x.reshape(B * T, D)
         g_w_hh = gh2.t() @ h_in.reshape(B * T, D)
         g_lin_w = torch.cat([dx2.t() @ z_in, dx2.t() @ a_vec], dim=1)
-        g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, (dx2 @ lin_wa) * c2)
+        g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, (dx2 @ lin_w[:, LK:]) * c2)
         g_fc = d_post.reshape(B * T, LK).t() @ h.reshape(B * T, D)
         return (None, d_post.reshape(B, T, LK), g_a_emb, g_lin_w, dx2.sum(0), g_w_ih, g_w_hh, gi2.sum(0), gh2.sum(0), g_fc,
                 None, None, None, None, None, None)

@@ -251,6 +251,38 @@ typedef struct drm_observe_io {
 size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, int32_t T);
 int drm_observe_forward_f32(const drm_observe_weights* w, const drm_observe_io* io, drm_stream_t stream);
 
+/* Reverse-time pass of the observe recurrence (what autograd's backward through the loop of
+ * lib/world_model.py:563-589 computes).  Inputs: the tensors saved by drm_observe_forward_f32,
+ * the upstream gradients wrt h (B,T,D), wrt the straight-through z (B,T,L,K) and wrt the
+ * posterior logits (B,T,L,K), and transposed copies of the recurrent weights.  Outputs: per-step
+ * d(gi), d(gh) (B,T,3D), d(x) (B,T,D) and d(post) (B,T,L*K); the weight gradients are products of
+ * these with the saved activations and are formed by the caller as large batched GEMMs.
+ *   wmix = exp(log_softmax(post) + log(1-eps) - log_unimix(post)),  psoft = softmax(post). */
+typedef struct drm_observe_bwd_io {
+    int32_t B, T;
+    const float* c_prev;      /* (B,T) */
+    const float* y;           /* (B,T,L*K) */
+    const float* wmix;        /* (B,T,L*K) */
+    const float* psoft;       /* (B,T,L*K) */
+    const float* gates;       /* (B,T,4D) */
+    const float* h_in;        /* (B,T,D) */
+    const float* g_h;         /* (B,T,D) upstream */
+    const float* g_z;         /* (B,T,L*K) upstream */
+    const float* g_post;      /* (B,T,L*K) upstream */
+    const float* fc_w_hT;     /* (D, L*K)  = enc.fc.0.weight[:, conv_out:]^T */
+    const float* gru_w_ihT;   /* (D, 3D)   = weight_ih^T */
+    const float* gru_w_hhT;   /* (D, 3D)   = weight_hh^T */
+    const float* lin_zT;      /* (L*K, D)  = seq.linear.weight[:, :L*K]^T (the forward pack's table) */
+    float* d_gi;              /* (B,T,3D) */
+    float* d_gh;              /* (B,T,3D) */
+    float* d_x;               /* (B,T,D) */
+    float* d_post;            /* (B,T,L*K) */
+    void* workspace; size_t workspace_bytes;   /* >= drm_observe_bwd_workspace_bytes */
+} drm_observe_bwd_io;
+
+size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t B);
+int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io, drm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
