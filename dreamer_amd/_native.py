@@ -239,7 +239,7 @@ def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int =
     return y
 
 
-PROF_CLASSES = 10
+PROF_CLASSES = 12
 
 
 def prof_enable(on: bool) -> None:

@@ -11,16 +11,24 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 }  // namespace drm
 
 namespace drm {
+// One event per launch, recorded right behind it; a launch's time runs from the previous launch's event
+// (same back-to-back run) to its own, i.e. what a kernel trace shows for kernels queued back to back.
 struct ProfRecord { int cls; hipEvent_t a, b; double flops, bytes; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static bool g_prof_fresh = true;
 static std::vector<ProfRecord> g_prof;
 bool prof_on() { return g_prof_on; }
+void prof_fresh() { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_fresh = true; }
 void prof_begin(int cls, hipStream_t s, double flops, double bytes) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRecord r{cls, nullptr, nullptr, flops, bytes};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    (void)hipEventRecord(r.a, s);
+    if (hipEventCreate(&r.b) != hipSuccess) return;
+    if (g_prof_fresh || g_prof.empty()) {
+        if (hipEventCreate(&r.a) != hipSuccess) return;
+        (void)hipEventRecord(r.a, s);
+        g_prof_fresh = false;
+    }
     g_prof.push_back(r);
 }
 void prof_end(hipStream_t s) {
@@ -28,8 +36,9 @@ void prof_end(hipStream_t s) {
     if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, s);
 }
 static void prof_clear() {
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& r : g_prof) { if (r.a) (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
+    g_prof_fresh = true;
 }
 }  // namespace drm
 
@@ -43,7 +52,7 @@ extern "C" int drm_prof_enable(int enable) {
 extern "C" const char* drm_prof_class_name(int cls) {
     static const char* names[DRM_PROF_CLASSES] = {"k_linear16<1,store>", "k_linear16<3,gru>", "k_linear16<2,sample>",
                                                   "k_actor_head_x", "k_scalar_heads", "k_critic_value", "k_lambda_return",
-                                                  "k_seq_gather", "k_sample_st", "pack"};
+                                                  "k_seq_gather", "k_sample_st", "pack", "k_linear_big", "elementwise"};
     return (cls >= 0 && cls < DRM_PROF_CLASSES) ? names[cls] : "";
 }
 
@@ -51,11 +60,12 @@ extern "C" int drm_prof_summary(int cls, double* total_ms, int64_t* launches, do
     DRM_REQUIRE(total_ms && launches && flops && bytes, DRM_EINVAL, "null pointer");
     std::lock_guard<std::mutex> lk(drm::g_prof_mu);
     *total_ms = 0; *launches = 0; *flops = 0; *bytes = 0;
-    for (auto& r : drm::g_prof) {
+    for (size_t i = 0; i < drm::g_prof.size(); ++i) {
+        auto& r = drm::g_prof[i];
         if (r.cls != cls) continue;
         DRM_HIP(hipEventSynchronize(r.b));
         float ms = 0.f;
-        DRM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        DRM_HIP(hipEventElapsedTime(&ms, r.a ? r.a : drm::g_prof[i - 1].b, r.b));
         *total_ms += ms; *launches += 1; *flops += r.flops; *bytes += r.bytes;
     }
     return DRM_OK;

@@ -34,10 +34,11 @@ void set_error(const std::string& msg);
 
 // kernel classes for the optional per-launch timing
 enum ProfClass { PC_LINEAR = 0, PC_GRU, PC_DYN_SAMPLE, PC_ACTOR_HEAD, PC_SCALAR_HEADS, PC_CRITIC_VALUE, PC_LAMBDA,
-                 PC_GATHER, PC_SAMPLE, PC_PACK };
+                 PC_GATHER, PC_SAMPLE, PC_PACK, PC_LINEAR_BIG, PC_ELEMENTWISE };
 bool prof_on();
 void prof_begin(int cls, hipStream_t s, double flops, double bytes);
 void prof_end(hipStream_t s);
+void prof_fresh();   // the next launch starts a new back-to-back run (gets a start event of its own)
 struct ProfScope {
     hipStream_t s; bool on;
     ProfScope(int cls, hipStream_t st, double flops, double bytes) : s(st), on(prof_on()) { if (on) prof_begin(cls, s, flops, bytes); }

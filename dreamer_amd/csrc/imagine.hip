@@ -3,6 +3,7 @@
 // the feature dimension (LayerNorm and the next matmul need whole rows), so each is a kernel
 // boundary; inside a kernel the output columns are spread over the CUs.
 #include "launch.hpp"
+#include "linear_big.hpp"
 
 #include <cstring>
 #include <mutex>
@@ -253,6 +254,103 @@ __global__ __launch_bounds__(256) void k_critic_value(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// large-row path helpers
+// ------------------------------------------------------------------------------------------------
+// unimix + Gumbel-argmax draw over complete logits (bias included), eight lanes per latent, writing into
+// the strided (B, H, ...) outputs of the rollout
+struct SampleRowsArgs {
+    const float* logits; int64_t ldlg;       // (B, L*32)
+    const float* expo; int64_t lde;
+    const uint8_t* forced; int64_t ldf;
+    uint8_t* idx_used; int64_t ldu;
+    uint8_t* idx_sampled; int64_t ldsm;
+    float* z_dense; int64_t ldzd;
+    float* logits_out; int64_t ldlo;
+    int B, L;
+    float log1m_eps, log_eps_over_k;
+};
+
+__global__ __launch_bounds__(256) void k_sample_rows(const SampleRowsArgs P) {
+    const int sub = threadIdx.x & 7;
+    const int64_t total = (int64_t)P.B * P.L;
+    for (int64_t it = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); it < total; it += (int64_t)gridDim.x * 32) {
+        const int b = (int)(it / P.L), l = (int)(it - (int64_t)b * P.L);
+        const float4 lg = *reinterpret_cast<const float4*>(P.logits + (int64_t)b * P.ldlg + l * 32 + sub * 4);
+        const float4 ex = *reinterpret_cast<const float4*>(P.expo + (int64_t)b * P.lde + l * 32 + sub * 4);
+        float v[4] = {lg.x, lg.y, lg.z, lg.w};
+        const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+        const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += expf(v[j] - mx);
+        const float lse = logf(group_sum<8>(s));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = logaddexp_f((v[j] - mx - lse) + P.log1m_eps, P.log_eps_over_k) - logf(e[j]);
+        const float smax = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float y[4];
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { y[j] = expf(v[j] - smax); s += y[j]; }
+        s = group_sum<8>(s);
+        float best = -1.f;
+        int bi = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = y[j] / s;
+            if (y[j] > best) { best = y[j]; bi = sub * 4 + j; }
+        }
+        group_argmax<8>(best, bi);
+        int used = bi;
+        if (P.forced) used = P.forced[(int64_t)b * P.ldf + l];
+        if (sub == 0) {
+            P.idx_used[(int64_t)b * P.ldu + l] = (uint8_t)used;
+            if (P.idx_sampled) P.idx_sampled[(int64_t)b * P.ldsm + l] = (uint8_t)bi;
+        }
+        const int k0 = sub * 4;
+        if (P.z_dense)
+            *reinterpret_cast<float4*>(P.z_dense + (int64_t)b * P.ldzd + l * 32 + k0) =
+                make_float4(used == k0 ? 1.f : 0.f, used == k0 + 1 ? 1.f : 0.f, used == k0 + 2 ? 1.f : 0.f, used == k0 + 3 ? 1.f : 0.f);
+        if (P.logits_out) *reinterpret_cast<float4*>(P.logits_out + (int64_t)b * P.ldlo + l * 32 + k0) = lg;
+    }
+}
+
+static int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
+                      hipStream_t stream) {
+    DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
+    BigLaunch L{};
+    int tiles = 0;
+    double fl = 0, by = 0;
+    for (int i = 0; i < np; ++i) {
+        const ProblemSpec& q = specs[i];
+        DRM_REQUIRE(q.X && q.W && q.Y && q.K >= 32 && q.K % 32 == 0 && q.N >= 1, DRM_EINVAL, "bad big problem");
+        DRM_REQUIRE(aligned16(q.X) && aligned16(q.W) && q.ldx % 4 == 0 && q.ldw % 4 == 0, DRM_EINVAL, "misaligned operand");
+        DRM_REQUIRE(!q.ln_g && !q.add && !q.rowscale, DRM_EINVAL, "large-row GEMM takes activated inputs");
+        DRM_REQUIRE(!q.tab || zidx, DRM_EINVAL, "gather table without indices");
+        BigProblem& p = L.p[i];
+        p.X = q.X; p.ldx = q.ldx; p.W = q.W; p.ldw = q.ldw; p.bias = q.bias; p.tab = q.tab; p.ldt = q.ldt;
+        p.Y = q.Y; p.ldy = q.ldy; p.N = q.N; p.K = q.K; p.tile_begin = tiles;
+        tiles += (q.N + BIG_BN - 1) / BIG_BN;
+        const double n = q.N, k = q.K, m = M;
+        fl += 2.0 * m * n * k + (q.tab ? (double)latents * m * n : 0.0);
+        by += 4.0 * (m * k + n * k + n + m * n) + (q.tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
+    }
+    L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
+    ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
+    k_linear_big<<<dim3(tiles, (M + BIG_BM - 1) / BIG_BM), dim3(256), 0, stream>>>(L);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+static int launch_ln_silu(const float* X, int64_t ldx, const float* g, const float* e, float* Y, int64_t ldy, int M, int K,
+                          hipStream_t stream) {
+    DRM_REQUIRE(K <= 512 && K % 4 == 0, DRM_ENOTSUP, "LayerNorm width %d", K);
+    ProfScope prof(PC_ELEMENTWISE, stream, 12.0 * M * K, 8.0 * M * K);
+    k_ln_silu_rows<<<dim3((M + 3) / 4), dim3(256), 0, stream>>>(X, ldx, g, e, Y, ldy, M, K);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
 static int check_dims(const drm_dims& d) {
     DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
     DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0 && d.D <= 512 && d.M <= 512, DRM_ENOTSUP,
@@ -282,8 +380,9 @@ static PackLayout pack_layout(const drm_dims& d) {
 }
 
 struct WsLayout {
-    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, total;   // offsets in floats
+    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, gi, logits, act[3], total;   // offsets in floats
 };
+constexpr int BIG_MIN_ROWS = 256;   // from this many trajectories on, the MFMA-bound large-row kernels are used
 static WsLayout ws_layout(const drm_dims& d, int B, int H) {
     WsLayout w{};
     size_t o = 0;
@@ -295,6 +394,11 @@ static WsLayout ws_layout(const drm_dims& d, int B, int H) {
     const size_t rows = (size_t)B * H;
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) w.head[i][j] = take(rows * d.M);
     w.critic_logits = take(rows * 256);
+    if (B >= BIG_MIN_ROWS) {
+        w.gi = take((size_t)B * 3 * d.D);
+        w.logits = take((size_t)B * d.L * d.K);
+        for (int i = 0; i < 3; ++i) w.act[i] = take(rows * d.M);
+    }
     w.total = o;
     return w;
 }
@@ -367,11 +471,28 @@ extern "C" int drm_fused_linear_f32(const drm_linear_args* a, drm_stream_t strea
     DRM_REQUIRE(a->M >= 1, DRM_EINVAL, "M=%d", a->M);
     DRM_REQUIRE(!a->table || (a->classes >= 1 && a->latents >= 1), DRM_EINVAL, "bad gather shape");
     ProblemSpec s{a->X, a->ldx, a->ln_gamma, a->ln_beta, a->W, a->ldw, a->bias, a->table, a->ldt, a->Y, a->ldy, a->N, a->K};
+    if (a->M >= BIG_MIN_ROWS && a->ln_gamma == nullptr)
+        return launch_big(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream);
     return launch_store(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream);
+}
+
+// One layer for up to 4 problems that share their rows: small-row kernels apply the producer's
+// LayerNorm + SiLU on load; the large-row kernels take activated inputs, so the activation is a pass
+// of its own into `act[i]` first.
+static int run_linear(ProblemSpec* p, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes, bool big,
+                      float* const* act, int act_ld, hipStream_t s) {
+    if (!big) return launch_store(p, np, M, zidx, ldz, latents, classes, s);
+    for (int i = 0; i < np; ++i) {
+        if (p[i].ln_g == nullptr) continue;
+        if (int rc = launch_ln_silu(p[i].X, p[i].ldx, p[i].ln_g, p[i].ln_b, act[i], act_ld, M, p[i].K, s)) return rc;
+        p[i].X = act[i]; p[i].ldx = act_ld; p[i].ln_g = nullptr; p[i].ln_b = nullptr;
+    }
+    return launch_big(p, np, M, zidx, ldz, latents, classes, s);
 }
 
 static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
     if (int rc = check_weights(*w)) return rc;
+    prof_fresh();
     const drm_dims& d = w->dims;
     const int B = io->B, H = io->H, D = d.D, M = d.M, L = d.L, LK = d.L * d.K, S = D + LK;
     DRM_REQUIRE(B >= 1 && H >= 1, DRM_EINVAL, "B=%d H=%d", B, H);
@@ -390,11 +511,13 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const float l1m = (float)log1p(-(double)d.unimix_eps);
     const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
     const float lea = (float)(log((double)d.unimix_eps) - log((double)d.A));
+    const bool big = B >= BIG_MIN_ROWS;
+    float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
 
     // gh for step 0
     {
         ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D};
-        if (int rc = launch_store(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+        if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, big, act, M, s)) return rc;
     }
     for (int t = 0; t < H; ++t) {
         const float* h_t = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D;
@@ -408,7 +531,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                                         ws + wl.a_pre[0], M, M, D};
             else p = ProblemSpec{ws + wl.a_pre[(i - 1) & 1], M, w->actor.ln_g[i - 1], w->actor.ln_b[i - 1], w->actor.w[i], M,
                                  w->actor.b[i], nullptr, 0, ws + wl.a_pre[i & 1], M, M, M};
-            if (int rc = launch_store(&p, 1, B, z_t, ldz, L, d.K, s)) return rc;
+            if (int rc = run_linear(&p, 1, B, z_t, ldz, L, d.K, big, act, M, s)) return rc;
         }
         // actor head, action draw, GRU input row
         {
@@ -435,25 +558,49 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
         }
         // GRU: gi = W_ih x, gates with the precomputed gh -> h_{t+1} written into h_out[:, t]
         float* h_new = io->h_out + (size_t)t * D;
-        {
+        if (!big) {
             ProblemSpec p{ws + wl.x, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, h_new, (int64_t)H * D, 3 * D, D};
             GruEpilogue G{w->gru_b_ih, ws + wl.gh, 3 * D, h_t, ldh, h_new, (int64_t)H * D, D, nullptr, 0, nullptr, nullptr, 0};
             if (int rc = launch_gru(p, B, G, s)) return rc;
+        } else {
+            ProblemSpec p{ws + wl.x, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, ws + wl.gi, 3 * D, 3 * D, D};
+            if (int rc = launch_big(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+            ProfScope prof(PC_ELEMENTWISE, s, 20.0 * B * D, 4.0 * 8.0 * B * D);
+            k_gru_gates<<<dim3((unsigned)(((int64_t)B * D + 255) / 256)), dim3(256), 0, s>>>(
+                ws + wl.gi, 3 * D, w->gru_b_ih, ws + wl.gh, 3 * D, h_t, ldh, h_new, (int64_t)H * D, B, D);
+            DRM_LAUNCH_CHECK();
         }
         // dyn layer 1 and (for the next step) gh = W_hh h_{t+1} + b_hh share their input
         {
             ProblemSpec p[2] = {
                 {h_new, (int64_t)H * D, nullptr, nullptr, w->dyn.w[0], D, w->dyn.b[0], nullptr, 0, ws + wl.d_pre[0], M, M, D},
                 {h_new, (int64_t)H * D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D}};
-            if (int rc = launch_store(p, t + 1 < H ? 2 : 1, B, nullptr, 0, 0, 0, s)) return rc;
+            if (int rc = run_linear(p, t + 1 < H ? 2 : 1, B, nullptr, 0, 0, 0, big, act, M, s)) return rc;
         }
         for (int i = 1; i < w->dyn.n_layers; ++i) {
             ProblemSpec p{ws + wl.d_pre[(i - 1) & 1], M, w->dyn.ln_g[i - 1], w->dyn.ln_b[i - 1], w->dyn.w[i], M, w->dyn.b[i],
                           nullptr, 0, ws + wl.d_pre[i & 1], M, M, M};
-            if (int rc = launch_store(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+            if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, big, act, M, s)) return rc;
         }
         // dyn head + unimix + Gumbel-argmax draw of z_{t+1}
-        {
+        if (big) {
+            const int last = w->dyn.n_layers - 1;
+            ProblemSpec p{ws + wl.d_pre[last & 1], M, w->dyn.ln_g[last], w->dyn.ln_b[last], w->dyn.head_w, M, w->dyn.head_b,
+                          nullptr, 0, ws + wl.logits, LK, LK, M};
+            if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, true, act, M, s)) return rc;
+            SampleRowsArgs a{};
+            a.logits = ws + wl.logits; a.ldlg = LK; a.expo = io->expo_z + (size_t)t * B * LK; a.lde = LK;
+            a.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.ldf = (int64_t)H * L;
+            a.idx_used = io->zidx_out + (size_t)t * L; a.ldu = (int64_t)H * L;
+            a.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.ldsm = (int64_t)H * L;
+            a.z_dense = io->z_out ? io->z_out + (size_t)t * LK : nullptr; a.ldzd = (int64_t)H * LK;
+            a.logits_out = io->prior_logits_out ? io->prior_logits_out + (size_t)t * LK : nullptr; a.ldlo = (int64_t)H * LK;
+            a.B = B; a.L = L; a.log1m_eps = l1m; a.log_eps_over_k = lek;
+            const int64_t blocks = ((int64_t)B * L + 31) / 32;
+            ProfScope prof(PC_SAMPLE, s, 40.0 * B * LK, (double)B * L * (256.0 + (a.z_dense ? 128.0 : 0.0) + 1.0));
+            k_sample_rows<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s>>>(a);
+            DRM_LAUNCH_CHECK();
+        } else {
             const int last = w->dyn.n_layers - 1;
             ProblemSpec p{ws + wl.d_pre[last & 1], M, w->dyn.ln_g[last], w->dyn.ln_b[last], w->dyn.head_w, M, w->dyn.head_b,
                           nullptr, 0, nullptr, 0, LK, M};
@@ -492,7 +639,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             }
         }
         if (np == 0) continue;
-        if (int rc = launch_store(p, np, rows, io->zidx_out, L, L, d.K, s)) return rc;
+        if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s)) return rc;
     }
     {
         ScalarHeadsArgs a{};

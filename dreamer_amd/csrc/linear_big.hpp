@@ -1,0 +1,269 @@
+// Large-row linear block on fp32 MFMA (v_mfma_f32_32x32x2_f32): the MFMA-bound regime
+// (thousands of trajectories, BASELINE config 3).
+//
+// Workgroup = 4 waves = a 64-row x 128-column output tile; waves are laid out 2 (rows) x 2 (columns),
+// each owning a 32 x 64 sub-tile = two 32x32 accumulators.  K is walked in steps of 32 through two LDS
+// buffers: while the MFMAs of step i run from one buffer, the global loads of step i+1 are in flight
+// into registers and are written to the other buffer afterwards (one barrier per step).
+//
+// LDS image: [row][k] with a row stride of 36 words for both operands (X rows and W rows are both
+// K-contiguous in memory, so the same 128-byte-per-row coalesced load shape fills both).  A lane reads
+// its operand as one 16-byte ds_read_b128 = four consecutive k; those four feed four MFMAs whose
+// instruction-level k index is lane>>5, i.e. the products are summed over k = kb + 4*(lane>>5) + s --
+// the same permutation of k for A and B, so the sum is unchanged.  With the 36-word stride the 16
+// lanes a ds_read_b128 services together touch 16 different 4-bank groups: no bank conflicts.
+//
+// Epilogue: + bias, + one-hot table rows (the z part of a Linear over cat[h, z]), store.
+#pragma once
+#include "common.hpp"
+
+namespace drm {
+
+struct BigProblem {
+    const float* X; int64_t ldx;     // (M, K)
+    const float* W; int64_t ldw;     // (N, K) torch Linear layout
+    const float* bias;               // (N) or nullptr
+    const float* tab; int64_t ldt;   // one-hot gather table [(l*classes + idx)][n] or nullptr
+    float* Y; int64_t ldy;
+    int N, K;
+    int tile_begin;                  // first blockIdx.x (column tile) of this problem
+};
+
+struct BigLaunch {
+    BigProblem p[4];
+    int np, M;
+    const uint8_t* zidx; int64_t ldz; int latents, classes;
+};
+
+constexpr int BIG_BM = 64, BIG_BN = 128, BIG_BK = 32, BIG_LD = 36;
+
+// One K-step (32 deep) of a wave's 32 x 64 sub-tile: 4 groups of 8 MFMAs.  The LDS reads of group
+// g+1 are issued before the MFMAs of group g, so they complete under them.
+#define BIG_FRAG(buf, g, A, B0, B1)                                                                   \
+    A = *reinterpret_cast<const float4*>(&sA[buf][wm * 32 + li][(g) * 8 + lh * 4]);                  \
+    B0 = *reinterpret_cast<const float4*>(&sB[buf][wn * 64 + li][(g) * 8 + lh * 4]);                 \
+    B1 = *reinterpret_cast<const float4*>(&sB[buf][wn * 64 + 32 + li][(g) * 8 + lh * 4]);
+#define BIG_MMA8(A, B0, B1)                                                                           \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B0.x, acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B1.x, acc1, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B0.y, acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B1.y, acc1, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B0.z, acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B1.z, acc1, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B0.w, acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B1.w, acc1, 0, 0, 0);
+#define BIG_STEP(buf)                                                                                 \
+    {                                                                                                 \
+        float4 fa0, fb00, fb10, fa1, fb01, fb11;                                                      \
+        BIG_FRAG(buf, 0, fa0, fb00, fb10)                                                             \
+        BIG_FRAG(buf, 1, fa1, fb01, fb11)                                                             \
+        BIG_MMA8(fa0, fb00, fb10)                                                                     \
+        BIG_FRAG(buf, 2, fa0, fb00, fb10)                                                             \
+        BIG_MMA8(fa1, fb01, fb11)                                                                     \
+        BIG_FRAG(buf, 3, fa1, fb01, fb11)                                                             \
+        BIG_MMA8(fa0, fb00, fb10)                                                                     \
+        BIG_MMA8(fa1, fb01, fb11)                                                                     \
+    }
+
+__global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
+    // one array: operand stages during the K loop, the output tile during the epilogue
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BIG_BM + BIG_BN) * BIG_LD];
+    float (*sA)[BIG_BM][BIG_LD] = reinterpret_cast<float (*)[BIG_BM][BIG_LD]>(smem);
+    float (*sB)[BIG_BN][BIG_LD] = reinterpret_cast<float (*)[BIG_BN][BIG_LD]>(smem + 2 * BIG_BM * BIG_LD);
+
+    // Blocks that share X rows (the column tiles of one row tile) are renumbered so that they are
+    // dispatched to the same XCD and meet in its L2 (blocks are dealt round-robin over the 8 XCDs;
+    // a speed choice only).
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    int lin = blockIdx.y * nbx + blockIdx.x;
+    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+    const int bx = lin % nbx, by = lin / nbx;
+
+    int pi = L.np - 1;
+    while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
+    const BigProblem& P = L.p[pi];
+    const int n0 = (bx - P.tile_begin) * BIG_BN;
+    const int m0 = by * BIG_BM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;            // wave position in the 2 x 2 grid
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = P.K;
+
+    // global -> register staging: 8 threads cover one 128-byte row segment (32 k)
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    const float* xa[2];
+    const float* wb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+
+    // two register stages in flight: the loads of K-step s+2 are issued while step s is multiplied, so a
+    // load has two whole steps (~4000 cycles) to arrive even with a single workgroup on the CU
+    const int nk = K / BIG_BK;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a00, a01, b00, b01, b02, b03;   // stage 0 (even K-steps)
+    float4 a10, a11, b10, b11, b12, b13;   // stage 1 (odd K-steps)
+#define BIG_LOAD(S, ko)                                                     \
+    a##S##0 = *reinterpret_cast<const float4*>(xa[0] + (ko));               \
+    a##S##1 = *reinterpret_cast<const float4*>(xa[1] + (ko));               \
+    b##S##0 = *reinterpret_cast<const float4*>(wb[0] + (ko));               \
+    b##S##1 = *reinterpret_cast<const float4*>(wb[1] + (ko));               \
+    b##S##2 = *reinterpret_cast<const float4*>(wb[2] + (ko));               \
+    b##S##3 = *reinterpret_cast<const float4*>(wb[3] + (ko));
+#define BIG_STORE(S, buf)                                                   \
+    *reinterpret_cast<float4*>(&sA[buf][srow][skq]) = a##S##0;              \
+    *reinterpret_cast<float4*>(&sA[buf][srow + 32][skq]) = a##S##1;         \
+    *reinterpret_cast<float4*>(&sB[buf][srow][skq]) = b##S##0;              \
+    *reinterpret_cast<float4*>(&sB[buf][srow + 32][skq]) = b##S##1;         \
+    *reinterpret_cast<float4*>(&sB[buf][srow + 64][skq]) = b##S##2;         \
+    *reinterpret_cast<float4*>(&sB[buf][srow + 96][skq]) = b##S##3;
+    BIG_LOAD(0, 0)
+    a10 = a11 = b10 = b11 = b12 = b13 = zero4;
+    if (nk > 1) { BIG_LOAD(1, BIG_BK) }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    for (int ks = 0; ks < nk; ks += 2) {
+        // even step: stage 0 registers -> LDS buffer 0
+        BIG_STORE(0, 0)
+        __syncthreads();
+        if (ks + 2 < nk) { BIG_LOAD(0, (ks + 2) * BIG_BK) }
+        BIG_STEP(0)
+        if (ks + 1 < nk) {
+            // odd step: stage 1 registers -> LDS buffer 1 (its last readers passed the barrier above)
+            BIG_STORE(1, 1)
+            __syncthreads();
+            if (ks + 3 < nk) { BIG_LOAD(1, (ks + 3) * BIG_BK) }
+            BIG_STEP(1)
+        }
+    }
+#undef BIG_LOAD
+#undef BIG_STORE
+
+    // ---- epilogue.  C layout of 32x32x2: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
+    // The tile goes through LDS so that every thread then owns 4 consecutive columns of a row:
+    // 16-byte table-row reads for the one-hot term and 16-byte coalesced stores.
+    __syncthreads();
+    float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem);   // 64 x 132 words
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = acc0[i];
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;            // 32 threads cover the 128 columns of a row
+    const int n = n0 + c4;
+    if (n >= P.N) return;
+    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) {
+        bias.x = P.bias[n];
+        if (n + 1 < P.N) bias.y = P.bias[n + 1];
+        if (n + 2 < P.N) bias.z = P.bias[n + 2];
+        if (n + 3 < P.N) bias.w = P.bias[n + 3];
+    }
+    for (int r = tid >> 5; r < BIG_BM; r += 8) {
+        const int m = m0 + r;
+        if (m >= L.M) break;
+        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
+        if (P.tab != nullptr) {
+            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
+            if (vec) {
+                for (int l = 0; l < L.latents; l += 8) {
+                    float4 u[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ll = min(l + j, L.latents - 1);
+                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
+                }
+            } else {
+                for (int l = 0; l < L.latents; ++l) {
+                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
+                    y.x += tb[0];
+                    if (n + 1 < P.N) y.y += tb[1];
+                    if (n + 2 < P.N) y.z += tb[2];
+                    if (n + 3 < P.N) y.w += tb[3];
+                }
+            }
+        }
+        float* out = P.Y + (int64_t)m * P.ldy + n;
+        if (vec) {
+            *reinterpret_cast<float4*>(out) = y;
+        } else {
+            out[0] = y.x;
+            if (n + 1 < P.N) out[1] = y.y;
+            if (n + 2 < P.N) out[2] = y.z;
+            if (n + 3 < P.N) out[3] = y.w;
+        }
+    }
+}
+
+// ---- elementwise companions of the large-row path ---------------------------------------------------
+// Y = SiLU(LayerNorm(X row)); one wave per row, K <= 512 kept in registers (two-pass statistics).
+__global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ X, int64_t ldx, const float* __restrict__ g,
+                                                       const float* __restrict__ e, float* __restrict__ Y, int64_t ldy,
+                                                       int M, int K) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const float* x = X + (int64_t)row * ldx;
+    float4 v[2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        v[i] = k < K ? *reinterpret_cast<const float4*>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = group_sum<64>(s) / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        if (k < K) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<64>(q) / (float)K + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        if (k < K) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + k);
+            const float4 ee = *reinterpret_cast<const float4*>(e + k);
+            float4 o;
+            o.x = silu_f((v[i].x - mean) * rstd * gg.x + ee.x);
+            o.y = silu_f((v[i].y - mean) * rstd * gg.y + ee.y);
+            o.z = silu_f((v[i].z - mean) * rstd * gg.z + ee.z);
+            o.w = silu_f((v[i].w - mean) * rstd * gg.w + ee.w);
+            *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + k) = o;
+        }
+    }
+}
+
+// h_new = GRU gates(gi (bias excluded), gh (bias included), h_prev), elementwise over (M, D)
+__global__ __launch_bounds__(256) void k_gru_gates(const float* __restrict__ gi, int64_t ldgi, const float* __restrict__ b_ih,
+                                                    const float* __restrict__ gh, int64_t ldgh,
+                                                    const float* __restrict__ h_prev, int64_t ldh, float* __restrict__ h_new,
+                                                    int64_t ldhn, int M, int D) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * D) return;
+    const int m = (int)(idx / D), j = (int)(idx - (int64_t)m * D);
+    const float* a = gi + (int64_t)m * ldgi;
+    const float* b = gh + (int64_t)m * ldgh;
+    const float rr = sigmoid_f(a[j] + b_ih[j] + b[j]);
+    const float uu = sigmoid_f(a[D + j] + b_ih[D + j] + b[D + j]);
+    const float nn = tanhf((a[2 * D + j] + b_ih[2 * D + j]) + rr * b[2 * D + j]);
+    h_new[(int64_t)m * ldhn + j] = (1.0f - uu) * nn + uu * h_prev[(int64_t)m * ldh + j];
+}
+
+}  // namespace drm

@@ -128,6 +128,7 @@ static ObsPack obs_pack_layout(const drm_dims& d) {
 
 static int observe_enqueue(const drm_observe_weights* w, const drm_observe_io* io, hipStream_t s) {
     if (int rc = check_observe_dims(w->dims)) return rc;
+    prof_fresh();
     const drm_dims& d = w->dims;
     const int B = io->B, T = io->T, D = d.D, L = d.L, LK = d.L * d.K;
     DRM_REQUIRE(B >= 1 && T >= 1, DRM_EINVAL, "B=%d T=%d", B, T);

@@ -52,7 +52,7 @@ int drm_arch_ok(void);
  * the stream it is launched on, and its algorithmic work (flops; bytes with every operand read
  * once and every result written once) is recorded under its kernel class.  drm_prof_enable(1)
  * clears earlier records; drm_prof_summary() waits for the recorded events. */
-#define DRM_PROF_CLASSES 10
+#define DRM_PROF_CLASSES 12
 int drm_prof_enable(int enable);
 const char* drm_prof_class_name(int cls);
 int drm_prof_summary(int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
