@@ -21,6 +21,26 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def init_from_env(device=None):
+    """Join the job a launcher (torchrun) described in the environment: WORLD_SIZE > 1 and no process
+    group yet -> one is created (RCCL for a GPU device, gloo for CPU).  Returns the device this rank
+    should use (``cuda:LOCAL_RANK`` when the configured device is a GPU)."""
+    import os
+    n = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if dev.type == "cuda":
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+    if n > 1 and dist.is_available() and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if dev.type == "cuda":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    return dev
+
+
 class FlatGrads:
     """Flat gradient buffer of a module.
 

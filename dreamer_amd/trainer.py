@@ -147,6 +147,8 @@ def _log(writer, learner: Learner, out, step: int, ups: float):
 
 
 def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        cfg.device = D.init_from_env(cfg.device)
     is_main = D.rank() == 0
     env = env if env is not None else make_env(cfg.env_id)
     act_space = env.action_space

@@ -2,7 +2,7 @@
 import csv, glob, sys
 d = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-f = sorted(glob.glob(d + "/*/*kernel_stats.csv"))[-1]
+f = sorted(glob.glob(d + "/**/*kernel_stats.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 print("total kernel ms", tot / 1e6, "kernels", sum(int(r["Calls"]) for r in rows))

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one round on the GPU box:
+#   kernel-trace stats of both bench workloads, then FETCH_SIZE and WRITE_SIZE passes (one pass each).
+# Usage (on the box, from the repo root):  bash tools/profile_round.sh r1
+set -e
+tag=${1:-r1}
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd /tmp
+export TMPDIR=/tmp
+
+stats() {  # name, bench args...
+    local name=$1; shift
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/$name" -o "$name" --output-format csv -- \
+        python3 "$root/bench.py" --no-cpu-baseline --train-steps 0 "$@" > "$out/$name.bench.json" 2> "$out/$name.err"
+    python3 "$root/tools/prof_summary.py" "$out/$name" 30 > "$out/$name.stats.txt"
+    find "$out/$name" -name '*kernel_trace.csv' -delete
+}
+
+pmc() {  # name, counter, bench args...
+    local name=$1; local ctr=$2; shift; shift
+    timeout -s KILL 200 rocprofv3 --pmc "$ctr" -d "$out/$name.$ctr" -o "$name" --output-format csv -- \
+        python3 "$root/bench.py" --no-cpu-baseline --train-steps 0 --profile-steps 0 "$@" > /dev/null 2> "$out/$name.$ctr.err"
+    python3 "$root/tools/pmc_summary.py" "$out/$name.$ctr" "$ctr" > "$out/$name.$ctr.txt"
+    rm -rf "$out/$name.$ctr"
+}
+
+stats imagine16 --workload imagine16
+stats imagine4096 --workload imagine4096 --steps 20 --warmup 3
+pmc imagine4096 FETCH_SIZE --workload imagine4096 --steps 3 --warmup 1
+pmc imagine4096 WRITE_SIZE --workload imagine4096 --steps 3 --warmup 1
+pmc imagine16 FETCH_SIZE --workload imagine16 --steps 10 --warmup 2
+pmc imagine16 WRITE_SIZE --workload imagine16 --steps 10 --warmup 2
+echo done
