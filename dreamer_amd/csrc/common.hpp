@@ -87,28 +87,56 @@ __device__ __forceinline__ float logaddexp_f(float a, float b) {
     return m + log1pf(expf(-fabsf(a - b)));
 }
 
-// reductions over the `width` consecutive lanes this lane belongs to (width a power of two <= 64)
+// ---- cross-lane exchange ---------------------------------------------------------------------------
+// Value of lane (this ^ M).  Partners up to 8 lanes away are reached with DPP modifiers on a plain
+// vector move (no LDS crossbar round trip): quad permutes for 1 and 2, half-row mirror followed by a
+// quad reverse for 4 (i -> 7-i -> (7-i)^3 = i^4), a row rotation by 8 for 8.  16 and 32 go through
+// ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int M>
+__device__ __forceinline__ float xor_lane(float v) {
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);                   // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);              // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror, quad_perm [3,2,1,0]
+    else if constexpr (M == 8) return dpp_mov<0x128>(v);             // row_ror:8
+    else return __shfl_xor(v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ int xor_lane_i(int v) { return __builtin_bit_cast(int, xor_lane<M>(__builtin_bit_cast(float, v))); }
+
+// reductions over the `width` consecutive lanes this lane belongs to (width a power of two <= 64);
+// every lane of the group receives the result
+#define DRM_LEVELS(OP)                                  \
+    if constexpr (WIDTH >= 2) { OP(1) }                 \
+    if constexpr (WIDTH >= 4) { OP(2) }                 \
+    if constexpr (WIDTH >= 8) { OP(4) }                 \
+    if constexpr (WIDTH >= 16) { OP(8) }                \
+    if constexpr (WIDTH >= 32) { OP(16) }               \
+    if constexpr (WIDTH >= 64) { OP(32) }
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WIDTH));
+#define DRM_OP(m) v = fmaxf(v, xor_lane<m>(v));
+    DRM_LEVELS(DRM_OP)
+#undef DRM_OP
     return v;
 }
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WIDTH);
+#define DRM_OP(m) v += xor_lane<m>(v);
+    DRM_LEVELS(DRM_OP)
+#undef DRM_OP
     return v;
 }
 // argmax with first-index tie break over a lane group
 template <int WIDTH>
 __device__ __forceinline__ void group_argmax(float& v, int& i) {
-#pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) {
-        float ov = __shfl_xor(v, o, WIDTH);
-        int oi = __shfl_xor(i, o, WIDTH);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+#define DRM_OP(m) { const float ov = xor_lane<m>(v); const int oi = xor_lane_i<m>(i); if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; } }
+    DRM_LEVELS(DRM_OP)
+#undef DRM_OP
 }
+#undef DRM_LEVELS
 
 }  // namespace drm

@@ -72,6 +72,7 @@ struct ActorHeadArgs {
     float log1m_eps, log_eps_over_a;
     const uint8_t* zidx; int64_t ldz; int latents, classes;
     const float* lin_zT; const float* lin_b; const float* a_tab; int D;
+    const float* xz; int64_t ldxz;           // when given: lin_b + the z table rows, already summed (B, D)
     float* x; int64_t ldxo;
     int64_t* a_used; int64_t ldau;
     int64_t* a_sampled; int64_t ldas;        // nullable
@@ -90,12 +91,14 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
     __shared__ int s_a;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    STAMP_DECL
+    STAMP();
     const float* pre = P.pre + (int64_t)b * P.ldp;
     const int i0 = tid, i1 = tid + 256;
     const bool on0 = i0 < P.M, on1 = i1 < P.M;
     const bool jn0 = i0 < P.D, jn1 = i1 < P.D;
     // ---- loads, level 1
-    if (tid < P.latents) s_z[tid] = P.zidx[(int64_t)b * P.ldz + tid];
+    if (tid < P.latents && P.xz == nullptr) s_z[tid] = P.zidx[(int64_t)b * P.ldz + tid];
     const float x0 = on0 ? pre[i0] : 0.f, x1 = on1 ? pre[i1] : 0.f;
     const float g0 = on0 ? P.ln_g[i0] : 0.f, g1 = on1 ? P.ln_g[i1] : 0.f;
     const float e0 = on0 ? P.ln_b[i0] : 0.f, e1 = on1 ? P.ln_b[i1] : 0.f;
@@ -110,17 +113,29 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
     }
     const float ex = lane < P.A ? P.expo[(int64_t)b * P.lde + lane] : 1.f;
     const float hb = lane < P.A ? P.head_b[lane] : 0.f;
-    float xz0 = jn0 ? P.lin_b[i0] : 0.f, xz1 = jn1 ? P.lin_b[i1] : 0.f;
+    const bool have_xz = P.xz != nullptr;
+    float xz0, xz1;
+    if (have_xz) {
+        xz0 = jn0 ? P.xz[(int64_t)b * P.ldxz + i0] : 0.f;
+        xz1 = jn1 ? P.xz[(int64_t)b * P.ldxz + i1] : 0.f;
+    } else {
+        xz0 = jn0 ? P.lin_b[i0] : 0.f;
+        xz1 = jn1 ? P.lin_b[i1] : 0.f;
+    }
     // ---- loads, level 2: table rows selected by z, all in flight together
     __syncthreads();
     float u0[LMAX], u1[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-        const bool ok = l < P.latents;
+        const bool ok = l < P.latents && !have_xz;
         const int64_t rowoff = ok ? (int64_t)(l * P.classes + s_z[l]) * P.D : 0;
         u0[l] = (ok && jn0) ? P.lin_zT[rowoff + i0] : 0.f;
         u1[l] = (ok && jn1) ? P.lin_zT[rowoff + i1] : 0.f;
     }
+#ifdef DRM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+#endif
     // ---- LayerNorm + SiLU
     const float mean = block_sum_256(x0 + x1, s4) / (float)P.M;
     const float d0 = on0 ? x0 - mean : 0.f, d1 = on1 ? x1 - mean : 0.f;
@@ -162,6 +177,8 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
         }
     }
     __syncthreads();
+    STAMP();
+    STAMP_FLUSH(2000ull);
     const int act = s_a;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) { xz0 += u0[l]; xz1 += u1[l]; }
@@ -172,6 +189,136 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
     }
     if (jn0) P.x[(int64_t)b * P.ldxo + i0] = xz0 + t0;
     if (jn1) P.x[(int64_t)b * P.ldxo + i1] = xz1 + t1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// few-row path: actor head + action draw + GRU cell, one workgroup per trajectory.
+//   act = SiLU(LN(pre));  logits = head(act);  logp = normalise(log_unimix(logits));  a = argmax(softmax(logp) / E)
+//   gi = gi_z + gi_a[a] + b_ih;  h' = GRUCell gates(gi, gh, h)
+// The GRU input row is x = lin_b + (z table rows) + a_tab[a], so W_ih x splits into a part that does
+// not need the action (gi_z, formed by an earlier launch while the policy MLP runs) and a row of the
+// precomputed table gi_a = W_ih a_tab^T chosen by the action: the recurrent step needs no matrix
+// product after the draw.  (lib/actor.py:94-106, Categorical.sample, lib/world_model.py:64-71)
+// ------------------------------------------------------------------------------------------------
+struct ActorGatesArgs {
+    const float* pre; int64_t ldp;
+    const float* ln_g; const float* ln_b;
+    const float* head_w; const float* head_b;
+    int M, A;
+    const float* expo; int64_t lde;          // (B, A)
+    const int64_t* forced; int64_t ldf;      // (B) strided or nullptr
+    float log1m_eps, log_eps_over_a;
+    const float* gi_z; int64_t ldgi;         // (B, 3D)
+    const float* gi_a;                       // (A, 3D)
+    const float* b_ih;                       // (3D)
+    const float* gh; int64_t ldgh;           // (B, 3D) = W_hh h + b_hh
+    const float* h_prev; int64_t ldh;
+    float* h_new; int64_t ldhn; int D;
+    int64_t* a_used; int64_t ldau;
+    int64_t* a_sampled; int64_t ldas;        // nullable
+    float* logp_out; int64_t ldlp;           // nullable
+};
+
+__device__ __forceinline__ float2 ld2(const float* p, bool on) {
+    return on ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
+}
+
+// M <= 512 and D <= 512 (both even): thread t owns features 2t, 2t+1 and hidden units 2t, 2t+1.
+template <int AMAX>
+__global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
+    __shared__ float s_st[4][2];
+    __shared__ float s_dot[4][AMAX];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    STAMP_DECL
+    STAMP();
+    const int i0 = 2 * tid;
+    const bool on = i0 < P.M, jn = i0 < P.D;
+    const int D = P.D;
+    // ---- loads that do not depend on the action
+    const float* pre = P.pre + (int64_t)b * P.ldp;
+    const float shift = pre[0];
+    const float2 xv = ld2(pre + i0, on);
+    const float2 gv = ld2(P.ln_g + i0, on), ev = ld2(P.ln_b + i0, on);
+    float2 hw[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) hw[a] = ld2(P.head_w + (int64_t)a * P.M + i0, on && a < P.A);
+    const int la = lane % AMAX;
+    const bool aon = la < P.A;
+    const float ex = aon ? P.expo[(int64_t)b * P.lde + la] : 1.f;
+    const float hb = aon ? P.head_b[la] : 0.f;
+    const float* giz = P.gi_z + (int64_t)b * P.ldgi;
+    const float* ghp = P.gh + (int64_t)b * P.ldgh;
+    const float2 gz_r = ld2(giz + i0, jn), gz_u = ld2(giz + D + i0, jn), gz_n = ld2(giz + 2 * D + i0, jn);
+    const float2 gh_r = ld2(ghp + i0, jn), gh_u = ld2(ghp + D + i0, jn), gh_n = ld2(ghp + 2 * D + i0, jn);
+    const float2 bi_r = ld2(P.b_ih + i0, jn), bi_u = ld2(P.b_ih + D + i0, jn), bi_n = ld2(P.b_ih + 2 * D + i0, jn);
+    const float2 hp = ld2(P.h_prev + (int64_t)b * P.ldh + i0, jn);
+    const int64_t forced = P.forced ? P.forced[(int64_t)b * P.ldf] : -1;
+#ifdef DRM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+#endif
+    // ---- LayerNorm (one pass, shifted by the row's first element) + SiLU
+    float st[2];
+    {
+        const float d0 = on ? xv.x - shift : 0.f, d1 = on ? xv.y - shift : 0.f;
+        st[0] = d0 + d1;
+        st[1] = fmaf(d0, d0, d1 * d1);
+    }
+    all_sum64<2>(st);
+    if (lane == 0) { s_st[wave][0] = st[0]; s_st[wave][1] = st[1]; }
+    __syncthreads();
+    const float inv_m = 1.0f / (float)P.M;
+    const float md = ((s_st[0][0] + s_st[1][0]) + (s_st[2][0] + s_st[3][0])) * inv_m;
+    const float var = fmaxf(((s_st[0][1] + s_st[1][1]) + (s_st[2][1] + s_st[3][1])) * inv_m - md * md, 0.f);
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    const float mean = shift + md;
+    const float a0 = on ? silu_f((xv.x - mean) * rstd * gv.x + ev.x) : 0.f;
+    const float a1 = on ? silu_f((xv.y - mean) * rstd * gv.y + ev.y) : 0.f;
+    // ---- head: per-thread partial dots, wave butterfly, cross-wave through LDS
+    float dot[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) dot[a] = fmaf(a0, hw[a].x, a1 * hw[a].y);
+    const float dsum = halving_sum64<AMAX>(dot, lane);
+    if (lane < AMAX) s_dot[wave][halving_index<AMAX>(lane)] = dsum;
+    __syncthreads();
+    // every group of AMAX lanes of every wave evaluates the policy (no broadcast of the action needed)
+    const float NEG = -3.0e38f;
+    const float lg = aon ? ((s_dot[0][la] + s_dot[1][la]) + (s_dot[2][la] + s_dot[3][la])) + hb : NEG;
+    const float mx = group_max<AMAX>(lg);
+    const float lse = logf(group_sum<AMAX>(aon ? expf(lg - mx) : 0.f));
+    const float mixed = aon ? logaddexp_f((lg - mx - lse) + P.log1m_eps, P.log_eps_over_a) : NEG;
+    // Categorical(logits=mixed) normalises once more
+    const float mx2 = group_max<AMAX>(mixed);
+    const float lse2 = mx2 + logf(group_sum<AMAX>(aon ? expf(mixed - mx2) : 0.f));
+    const float logp = mixed - lse2;
+    // probs = softmax(logp); multinomial draws argmax(probs / E)
+    const float mx3 = group_max<AMAX>(aon ? logp : NEG);
+    const float pe = aon ? expf(logp - mx3) : 0.f;
+    const float prob = pe / group_sum<AMAX>(pe);
+    float score = aon ? prob / ex : -1.f;
+    int ai = la;
+    group_argmax<AMAX>(score, ai);
+    const int used = forced >= 0 ? (int)forced : ai;
+    if (tid < P.A && P.logp_out) P.logp_out[(int64_t)b * P.ldlp + tid] = logp;
+    if (tid == 0) {
+        P.a_used[(int64_t)b * P.ldau] = used;
+        if (P.a_sampled) P.a_sampled[(int64_t)b * P.ldas] = ai;
+    }
+    STAMP();
+    // ---- GRU cell with the action's rows of gi_a
+    const float* ga = P.gi_a + (int64_t)used * 3 * D;
+    const float2 ga_r = ld2(ga + i0, jn), ga_u = ld2(ga + D + i0, jn), ga_n = ld2(ga + 2 * D + i0, jn);
+    if (!jn) return;
+    const float r0 = sigmoid_f(((gz_r.x + ga_r.x) + bi_r.x) + gh_r.x), r1 = sigmoid_f(((gz_r.y + ga_r.y) + bi_r.y) + gh_r.y);
+    const float u0 = sigmoid_f(((gz_u.x + ga_u.x) + bi_u.x) + gh_u.x), u1 = sigmoid_f(((gz_u.y + ga_u.y) + bi_u.y) + gh_u.y);
+    const float n0 = tanhf(((gz_n.x + ga_n.x) + bi_n.x) + r0 * gh_n.x), n1 = tanhf(((gz_n.y + ga_n.y) + bi_n.y) + r1 * gh_n.y);
+    float2 out;
+    out.x = (1.0f - u0) * n0 + u0 * hp.x;
+    out.y = (1.0f - u1) * n1 + u1 * hp.y;
+    *reinterpret_cast<float2*>(P.h_new + (int64_t)b * P.ldhn + i0) = out;
+    STAMP();
+    STAMP_FLUSH(2000ull);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,6 +462,116 @@ __global__ __launch_bounds__(256) void k_sample_rows(const SampleRowsArgs P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// few-row path: draw z for one trajectory, then apply every one-hot table that consumes it
+// ------------------------------------------------------------------------------------------------
+// Workgroup (slice, b): draws all L latents of trajectory b (1024 logits: four per thread, every
+// workgroup of the row repeats this small amount of work rather than wait for another one), then
+// forms its slice of columns of
+//     out_g[b, n] = base_g[b or 0, n] + sum_l tab_g[(l*32 + z[b, l]), n]         g = 0, 1
+// which are the z part of the actor's first Linear (added to the h part computed earlier) and the
+// GRU input row without its action term (lib/actor.py:94-99, lib/world_model.py:64-70 with z one-hot).
+struct GatherJob {
+    const float* tab; int64_t ldt;
+    const float* base; int64_t ldb;     // row stride of base (0: one vector for every row)
+    float* out; int64_t ldo;
+    int N, cw;                          // columns, columns per slice (multiple of 4)
+};
+struct SampleGatherArgs {
+    SampleRowsArgs s;                   // logits == nullptr: no draw, z = forced
+    GatherJob g[2];
+    int ng;
+    float one_m_eps, eps_over_k;        // 1 - unimix_eps, unimix_eps / K
+};
+
+__global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P) {
+    __shared__ uint8_t s_z[64];
+    __shared__ __attribute__((aligned(16))) float s_red[2][1024];
+    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+    const SampleRowsArgs& S = P.s;
+    const int sub = tid & 7;
+    STAMP_DECL
+    STAMP();
+    for (int l = tid >> 3; l < S.L; l += 32) {
+        int used, bi = 0;
+        float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (S.logits != nullptr) {
+            lg = *reinterpret_cast<const float4*>(S.logits + (int64_t)b * S.ldlg + l * 32 + sub * 4);
+            const float4 ex = *reinterpret_cast<const float4*>(S.expo + (int64_t)b * S.lde + l * 32 + sub * 4);
+            // argmax_k softmax(log_unimix(logits) - log E)_k = argmax_k ((1-eps) softmax(logits)_k + eps/K) / E_k:
+            // the draw needs no logarithm (the log-domain form of lib/world_model.py:459-461 is
+            // monotone in this ratio)
+            const float v[4] = {lg.x, lg.y, lg.z, lg.w};
+            const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+            const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            float pj[4], s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pj[j] = expf(v[j] - mx); s += pj[j]; }
+            const float scale = P.one_m_eps / group_sum<8>(s);
+            float best = -1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float q = fmaf(pj[j], scale, P.eps_over_k) / e[j];
+                if (q > best) { best = q; bi = sub * 4 + j; }
+            }
+            group_argmax<8>(best, bi);
+            used = bi;
+            if (S.forced) used = S.forced[(int64_t)b * S.ldf + l];
+        } else {
+            used = S.forced[(int64_t)b * S.ldf + l];
+        }
+        if (sub == 0) s_z[l] = (uint8_t)used;
+        if (slice == 0 && S.logits != nullptr) {
+            if (sub == 0) {
+                if (S.idx_used) S.idx_used[(int64_t)b * S.ldu + l] = (uint8_t)used;
+                if (S.idx_sampled) S.idx_sampled[(int64_t)b * S.ldsm + l] = (uint8_t)bi;
+            }
+            const int k0 = sub * 4;
+            if (S.z_dense)
+                *reinterpret_cast<float4*>(S.z_dense + (int64_t)b * S.ldzd + l * 32 + k0) =
+                    make_float4(used == k0 ? 1.f : 0.f, used == k0 + 1 ? 1.f : 0.f, used == k0 + 2 ? 1.f : 0.f, used == k0 + 3 ? 1.f : 0.f);
+            if (S.logits_out) *reinterpret_cast<float4*>(S.logits_out + (int64_t)b * S.ldlo + l * 32 + k0) = lg;
+        }
+    }
+    if (P.ng == 0) return;
+    __syncthreads();
+    STAMP();
+    // table rows: (cw / 4) threads cover a slice of one table row, 256 / (cw / 4) latents in flight
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        if (gi >= P.ng) break;
+        const GatherJob& J = P.g[gi];
+        const int tpr = J.cw >> 2;                  // threads per table-row slice
+        const int lpp = 256 / tpr;                  // latents per pass
+        const int ls = tid / tpr, c4 = (tid - ls * tpr) * 4;
+        const int n = slice * J.cw + c4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ls < lpp && n < J.N) {
+            for (int l = ls; l < S.L; l += lpp) {
+                const float4 u = *reinterpret_cast<const float4*>(J.tab + (int64_t)(l * 32 + s_z[l]) * J.ldt + n);
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            }
+        }
+        if (ls < lpp) *reinterpret_cast<float4*>(&s_red[gi][ls * J.cw + c4]) = a;
+    }
+    __syncthreads();
+    STAMP();
+    STAMP_FLUSH(3000ull);
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        if (gi >= P.ng) break;
+        const GatherJob& J = P.g[gi];
+        const int lpp = 256 / (J.cw >> 2);
+        const int n = slice * J.cw + tid;
+        if (tid < J.cw && n < J.N) {
+            float a = J.base[(int64_t)b * J.ldb + n];
+            const int live = lpp < S.L ? lpp : S.L;
+            for (int i = 0; i < live; ++i) a += s_red[gi][i * J.cw + tid];
+            J.out[(int64_t)b * J.ldo + n] = a;
+        }
+    }
+}
+
 static int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                       hipStream_t stream) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
@@ -363,7 +620,7 @@ static int check_dims(const drm_dims& d) {
 }
 
 struct PackLayout {
-    size_t actor_zT, critic_zT, rew_zT, cont_zT, lin_zT, a_tab, total;   // offsets in floats
+    size_t actor_zT, critic_zT, rew_zT, cont_zT, lin_zT, a_tab, gi_a, total;   // offsets in floats
 };
 static PackLayout pack_layout(const drm_dims& d) {
     PackLayout p{};
@@ -375,12 +632,14 @@ static PackLayout pack_layout(const drm_dims& d) {
     p.cont_zT = o; o += LK * d.M;
     p.lin_zT = o; o += LK * d.D;
     p.a_tab = o; o += (size_t)d.A * d.D;
+    o = (o + 3) & ~(size_t)3;
+    p.gi_a = o; o += (size_t)d.A * 3 * d.D;
     p.total = (o + 3) & ~(size_t)3;
     return p;
 }
 
 struct WsLayout {
-    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, gi, logits, act[3], total;   // offsets in floats
+    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, gi, logits, act[3], a1h, xz, total;   // offsets in floats
 };
 constexpr int BIG_MIN_ROWS = 256;   // from this many trajectories on, the MFMA-bound large-row kernels are used
 static WsLayout ws_layout(const drm_dims& d, int B, int H) {
@@ -398,6 +657,12 @@ static WsLayout ws_layout(const drm_dims& d, int B, int H) {
         w.gi = take((size_t)B * 3 * d.D);
         w.logits = take((size_t)B * d.L * d.K);
         for (int i = 0; i < 3; ++i) w.act[i] = take(rows * d.M);
+    }
+    if (B <= SKINNY_MAX_ROWS) {
+        w.gi = take((size_t)B * 3 * d.D);
+        w.logits = take((size_t)B * d.L * d.K);
+        w.a1h = take((size_t)B * d.M);
+        w.xz = take((size_t)B * d.D);
     }
     w.total = o;
     return w;
@@ -449,16 +714,21 @@ extern "C" int drm_pack_imagine(const drm_imagine_weights* w, float* pack_out, s
         {w->actor.w[0], S, d.D, d.M, pl.actor_zT}, {w->critic.w[0], S, d.D, d.M, pl.critic_zT},
         {w->rew.w[0], S, d.D, d.M, pl.rew_zT},     {w->cont.w[0], S, d.D, d.M, pl.cont_zT},
         {w->lin_w, LK + d.E, 0, d.D, pl.lin_zT}};
-    ProfScope prof(PC_PACK, s, 2.0 * d.A * d.D * d.E, 8.0 * ((double)LK * (4.0 * d.M + d.D)) + 4.0 * d.A * d.D);
-    for (auto& j : jobs) {
-        k_transpose_cols<<<dim3((LK + 31) / 32, (j.nrows + 31) / 32), dim3(256), 0, s>>>(j.W, j.ldw, j.col0, LK, j.nrows,
-                                                                                         pack_out + j.off);
+    {
+        ProfScope prof(PC_PACK, s, 2.0 * d.A * d.D * d.E, 8.0 * ((double)LK * (4.0 * d.M + d.D)) + 4.0 * d.A * d.D);
+        for (auto& j : jobs) {
+            k_transpose_cols<<<dim3((LK + 31) / 32, (j.nrows + 31) / 32), dim3(256), 0, s>>>(j.W, j.ldw, j.col0, LK, j.nrows,
+                                                                                             pack_out + j.off);
+            DRM_LAUNCH_CHECK();
+        }
+        k_action_table<<<dim3((d.D + 255) / 256, d.A), dim3(256), 0, s>>>(w->lin_w, LK + d.E, LK, d.E, w->a_emb, d.A, d.D,
+                                                                           pack_out + pl.a_tab);
         DRM_LAUNCH_CHECK();
     }
-    k_action_table<<<dim3((d.D + 255) / 256, d.A), dim3(256), 0, s>>>(w->lin_w, LK + d.E, LK, d.E, w->a_emb, d.A, d.D,
-                                                                       pack_out + pl.a_tab);
-    DRM_LAUNCH_CHECK();
-    return DRM_OK;
+    // gi_a[a] = W_ih a_tab[a]: the action's share of the GRU input product, one row per action
+    ProblemSpec g{pack_out + pl.a_tab, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
+                  pack_out + pl.gi_a, 3 * d.D, 3 * d.D, d.D};
+    return launch_skinny(&g, 1, d.A, s);
 }
 
 extern "C" size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H) {
@@ -514,6 +784,105 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const bool big = B >= BIG_MIN_ROWS;
     float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
 
+    const bool few = B <= SKINNY_MAX_ROWS;
+    if (few) {
+        // ---- few-row path: every layer is cut into ~256 workgroups; the draw of z and the one-hot
+        // tables it selects (actor layer 1, GRU input) share one launch
+        const int last_a = w->actor.n_layers - 1, last_d = w->dyn.n_layers - 1;
+        auto sample_gather = [&](int t, bool draw, bool gather) -> int {
+            SampleGatherArgs a{};
+            a.s.B = B; a.s.L = L; a.s.log1m_eps = l1m; a.s.log_eps_over_k = lek;
+            a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
+            if (draw) {
+                a.s.logits = ws + wl.logits; a.s.ldlg = LK; a.s.expo = io->expo_z + (size_t)t * B * LK; a.s.lde = LK;
+                a.s.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.s.ldf = (int64_t)H * L;
+                a.s.idx_used = io->zidx_out + (size_t)t * L; a.s.ldu = (int64_t)H * L;
+                a.s.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.s.ldsm = (int64_t)H * L;
+                a.s.z_dense = io->z_out ? io->z_out + (size_t)t * LK : nullptr; a.s.ldzd = (int64_t)H * LK;
+                a.s.logits_out = io->prior_logits_out ? io->prior_logits_out + (size_t)t * LK : nullptr; a.s.ldlo = (int64_t)H * LK;
+            } else {
+                a.s.forced = io->zidx0; a.s.ldf = L;
+            }
+            int slices = 1;
+            if (gather) {
+                // columns per slice so that B x slices is about the number of CUs
+                const int nmax = M > D ? M : D;
+                int cw = 4;
+                while (cw < 64 && (int64_t)B * ((nmax + cw - 1) / cw) > 320) cw *= 2;
+                slices = (nmax + cw - 1) / cw;
+                a.ng = 2;
+                a.g[0] = GatherJob{pack + pl.actor_zT, M, ws + wl.a1h, M, ws + wl.a_pre[0], M, M, cw};
+                a.g[1] = GatherJob{pack + pl.lin_zT, D, w->lin_b, 0, ws + wl.xz, D, D, cw};
+            }
+            ProfScope prof(PC_SAMPLE, s, (draw ? 40.0 * B * LK : 0.0) + (gather ? (double)B * L * (M + D) : 0.0),
+                           (draw ? (double)B * L * (256.0 + (a.s.z_dense ? 128.0 : 0.0) + 1.0) : 0.0) +
+                               (gather ? 4.0 * B * (L + 2.0) * (M + D) : 0.0));
+            k_sample_gather<<<dim3(slices, B), dim3(256), 0, s>>>(a);
+            DRM_LAUNCH_CHECK();
+            return DRM_OK;
+        };
+        {
+            ProblemSpec p[2] = {
+                {io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D},
+                {io->h0, D, nullptr, nullptr, w->actor.w[0], S, w->actor.b[0], nullptr, 0, ws + wl.a1h, M, M, D}};
+            if (int rc = launch_skinny(p, 2, B, s)) return rc;
+            if (int rc = sample_gather(0, false, true)) return rc;
+        }
+        for (int t = 0; t < H; ++t) {
+            const float* h_t = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D;
+            const int64_t ldh = t == 0 ? D : (int64_t)H * D;
+            // policy MLP; the action-free part of the GRU input product rides along with its first launch
+            const ProblemSpec giz{ws + wl.xz, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, ws + wl.gi, 3 * D, 3 * D, D};
+            if (last_a == 0) {
+                if (int rc = launch_skinny(&giz, 1, B, s)) return rc;
+            }
+            for (int i = 1; i <= last_a; ++i) {
+                ProblemSpec p[2] = {{ws + wl.a_pre[(i - 1) & 1], M, w->actor.ln_g[i - 1], w->actor.ln_b[i - 1], w->actor.w[i], M,
+                                     w->actor.b[i], nullptr, 0, ws + wl.a_pre[i & 1], M, M, M},
+                                    giz};
+                if (int rc = launch_skinny(p, i == 1 ? 2 : 1, B, s)) return rc;
+            }
+            float* h_new = io->h_out + (size_t)t * D;
+            {
+                ActorGatesArgs a{};
+                a.pre = ws + wl.a_pre[last_a & 1]; a.ldp = M;
+                a.ln_g = w->actor.ln_g[last_a]; a.ln_b = w->actor.ln_b[last_a];
+                a.head_w = w->actor.head_w; a.head_b = w->actor.head_b; a.M = M; a.A = d.A;
+                a.expo = io->expo_a + (size_t)t * B * d.A; a.lde = d.A;
+                a.forced = io->forced_actions ? io->forced_actions + t : nullptr; a.ldf = H;
+                a.log1m_eps = l1m; a.log_eps_over_a = lea;
+                a.gi_z = ws + wl.gi; a.ldgi = 3 * D; a.gi_a = pack + pl.gi_a; a.b_ih = w->gru_b_ih;
+                a.gh = ws + wl.gh; a.ldgh = 3 * D; a.h_prev = h_t; a.ldh = ldh; a.h_new = h_new; a.ldhn = (int64_t)H * D; a.D = D;
+                a.a_used = io->actions_out + t; a.ldau = H;
+                a.a_sampled = io->actions_sampled_out ? io->actions_sampled_out + t : nullptr; a.ldas = H;
+                a.logp_out = io->actor_logp_out ? io->actor_logp_out + (size_t)t * d.A : nullptr; a.ldlp = (int64_t)H * d.A;
+                ProfScope prof(PC_ACTOR_HEAD, s, 2.0 * B * M * d.A + 14.0 * B * D,
+                               4.0 * ((double)B * M + (double)d.A * M + 2.0 * M + (double)B * D * 11.0 + 3.0 * D));
+                if (d.A <= 8) k_actor_gates<8><<<dim3(B), dim3(256), 0, s>>>(a);
+                else k_actor_gates<32><<<dim3(B), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+            {
+                const bool more = t + 1 < H;
+                ProblemSpec p[3] = {
+                    {h_new, (int64_t)H * D, nullptr, nullptr, w->dyn.w[0], D, w->dyn.b[0], nullptr, 0, ws + wl.d_pre[0], M, M, D},
+                    {h_new, (int64_t)H * D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D},
+                    {h_new, (int64_t)H * D, nullptr, nullptr, w->actor.w[0], S, w->actor.b[0], nullptr, 0, ws + wl.a1h, M, M, D}};
+                if (int rc = launch_skinny(p, more ? 3 : 1, B, s)) return rc;
+            }
+            for (int i = 1; i <= last_d; ++i) {
+                ProblemSpec p{ws + wl.d_pre[(i - 1) & 1], M, w->dyn.ln_g[i - 1], w->dyn.ln_b[i - 1], w->dyn.w[i], M, w->dyn.b[i],
+                              nullptr, 0, ws + wl.d_pre[i & 1], M, M, M};
+                if (int rc = launch_skinny(&p, 1, B, s)) return rc;
+            }
+            {
+                ProblemSpec p{ws + wl.d_pre[last_d & 1], M, w->dyn.ln_g[last_d], w->dyn.ln_b[last_d], w->dyn.head_w, M,
+                              w->dyn.head_b, nullptr, 0, ws + wl.logits, LK, LK, M};
+                if (int rc = launch_skinny(&p, 1, B, s)) return rc;
+            }
+            if (int rc = sample_gather(t, true, t + 1 < H)) return rc;
+        }
+    } else {
     // gh for step 0
     {
         ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D};
@@ -615,6 +984,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             E.log1m_eps = l1m; E.log_eps_over_k = lek;
             if (int rc = launch_sample(p, B, L, E, s)) return rc;
         }
+    }
     }
 
     // ---- heads over all B*H imagined states ----

@@ -2,6 +2,7 @@
 // observe drivers).
 #pragma once
 #include "linear16.hpp"
+#include "linear_skinny.hpp"
 
 namespace drm {
 
@@ -150,6 +151,66 @@ static inline int launch_stbwd(const ProblemSpec& spec, int M, int latents, cons
         case 2: k_linear16<2, EPI_STBWD, 2><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, E); break;
         default: k_linear16<2, EPI_STBWD, 4><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, E); break;
     }
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+// ---- few-row path ---------------------------------------------------------------------------------
+// Problems of one launch share their rows and the (RW, CP) shape; LayerNorm is per problem.
+constexpr int SKINNY_MAX_ROWS = 64;    // above this many rows the MFMA tiles are the better cut
+
+static inline bool skinny_ok(const ProblemSpec& s) {
+    return s.K <= 512 && s.tab == nullptr && s.add == nullptr && s.rowscale == nullptr;
+}
+
+template <int RW>
+static inline void skinny_dispatch(int cp, dim3 grid, hipStream_t stream, const SkinnyLaunch& L) {
+    if (cp == 8) k_skinny<RW, 8><<<grid, dim3(256), 0, stream>>>(L);
+    else if (cp == 4) k_skinny<RW, 4><<<grid, dim3(256), 0, stream>>>(L);
+    else k_skinny<RW, 2><<<grid, dim3(256), 0, stream>>>(L);
+}
+
+// rows per workgroup (4 * RW): fewer rows mean less input to fetch and activate per workgroup, more
+// columns (cold weight bytes) each; LayerNorm problems lean to fewer rows
+static inline int skinny_rw(int M, bool has_ln) {
+    if (M <= 4) return 1;
+    if (M <= 8 || has_ln) return 2;
+    return 4;
+}
+
+static inline int launch_skinny(const ProblemSpec* specs, int np, int M, hipStream_t stream) {
+    DRM_REQUIRE(np >= 1 && np <= SKINNY_MAX_PROBLEMS && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
+    SkinnyLaunch L{};
+    bool has_ln = false;
+    int ntot = 0;
+    double fl = 0, by = 0;
+    for (int i = 0; i < np; ++i) {
+        if (int rc = check_problem(specs[i])) return rc;
+        DRM_REQUIRE(skinny_ok(specs[i]), DRM_ENOTSUP, "problem %d does not fit the few-row kernel", i);
+        has_ln = has_ln || specs[i].ln_g != nullptr;
+        ntot += specs[i].N;
+        const double n = specs[i].N, k = specs[i].K, m = M;
+        fl += 2.0 * m * n * k;
+        by += 4.0 * (m * k + n * k + n + m * n);
+    }
+    const int rw = skinny_rw(M, has_ln);
+    const int tiles_m = (M + 4 * rw - 1) / (4 * rw);
+    int cp = 2;
+    while (cp < 8 && (int64_t)tiles_m * ((ntot + cp - 1) / cp) > 384) cp *= 2;
+    int wgs = 0;
+    for (int i = 0; i < np; ++i) {
+        SkinnyProblem& p = L.p[i];
+        p.X = specs[i].X; p.ldx = specs[i].ldx; p.ln_g = specs[i].ln_g; p.ln_b = specs[i].ln_b;
+        p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.Y = specs[i].Y; p.ldy = specs[i].ldy;
+        p.N = specs[i].N; p.K = specs[i].K; p.wg_begin = wgs;
+        wgs += (specs[i].N + cp - 1) / cp;
+    }
+    L.np = np; L.M = M;
+    ProfScope prof(PC_LINEAR, stream, fl, by);
+    const dim3 grid(wgs, tiles_m);
+    if (rw == 1) skinny_dispatch<1>(cp, grid, stream, L);
+    else if (rw == 2) skinny_dispatch<2>(cp, grid, stream, L);
+    else skinny_dispatch<4>(cp, grid, stream, L);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

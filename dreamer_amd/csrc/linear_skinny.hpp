@@ -1,0 +1,198 @@
+// Few-row linear block for the latency-bound regime (a handful of trajectories, BASELINE config 2).
+//
+// With 16 rows a 512 x 512 layer is 8 MFLOP against 1 MB of weights: nothing is compute-bound, and a
+// launch costs what its slowest workgroup needs to FETCH.  A CU sustains only a few tens of GB/s on
+// loads that miss L2 (weights are cold in L2 at every kernel start), so the layer is cut into as many
+// workgroups as there are CUs: each workgroup owns CP output columns (2..8) and 4*RW rows, i.e. it
+// fetches CP weight rows (a few KB, cold) plus its input rows (hot in L2: every workgroup of the launch
+// reads the same ones).  The products run on the vector ALUs -- an MFMA tile would need 16 columns per
+// workgroup, which is 8x fewer workgroups and 8x more cold bytes each.
+//
+// Work split: wave w of the 4 owns rows 4*RW*tile + RW*w .. +RW-1 (all CP columns, all of K); lane l
+// owns k = 4l..4l+3 and 256+4l..256+4l+3 (K <= 512), so every global load is a full 16-byte-per-lane
+// row read.  Waves never talk to each other: LayerNorm statistics and the K-reduction of the RW*CP
+// partial sums are wave-level butterflies in which the number of live values halves per step, so a
+// reduction of NV values costs NV-1 + (6 - log2 NV) shuffles.  No LDS, no barrier.
+#pragma once
+#include "common.hpp"
+
+namespace drm {
+
+constexpr int SKINNY_MAX_PROBLEMS = 4;
+
+struct SkinnyProblem {
+    const float* X; int64_t ldx;               // (M, K)
+    const float* ln_g; const float* ln_b;     // LayerNorm + SiLU on X rows when ln_g != nullptr
+    const float* W; int64_t ldw;               // (N, K) torch Linear layout
+    const float* bias;                         // (N) or nullptr
+    float* Y; int64_t ldy;
+    int N, K;
+    int wg_begin;                              // first blockIdx.x of this problem
+};
+
+struct SkinnyLaunch {
+    SkinnyProblem p[SKINNY_MAX_PROBLEMS];
+    int np, M;
+};
+
+// Sum over the 64 lanes of a wave of each of NV per-lane values (NV = 2^LG <= 64) with a butterfly in
+// which the number of live values halves per level: level j pairs lane ^ 2^j, the lane whose bit j is
+// set keeps the upper half of the values and sends the lower half (the other lane the reverse), both
+// add what they receive.  The most exchanges happen at the levels with the cheapest partner
+// (xor_lane<1>, <2>: one DPP move).  Returns, on every lane, the total of value number
+//   idx(lane) = sum_{j < LG} bit_j(lane) << (LG - 1 - j);
+// lanes 0 .. NV-1 hold one total each, the other lanes repeat them.
+template <int NV>
+__device__ __forceinline__ float halving_sum64(float (&v)[NV], int lane) {
+    constexpr int LG = NV >= 64 ? 6 : NV >= 32 ? 5 : NV >= 16 ? 4 : NV >= 8 ? 3 : NV >= 4 ? 2 : NV >= 2 ? 1 : 0;
+#define DRM_HALVE(j)                                                        \
+    if constexpr (LG > (j)) {                                               \
+        constexpr int n = NV >> (j);                                        \
+        const bool up = (lane & (1 << (j))) != 0;                           \
+        _Pragma("unroll") for (int i = 0; i < n / 2; ++i) {                 \
+            const float keep = up ? v[i + n / 2] : v[i];                    \
+            const float send = up ? v[i] : v[i + n / 2];                    \
+            v[i] = keep + xor_lane<(1 << (j))>(send);                       \
+        }                                                                   \
+    } else {                                                                \
+        v[0] += xor_lane<(1 << (j))>(v[0]);                                 \
+    }
+    DRM_HALVE(0) DRM_HALVE(1) DRM_HALVE(2) DRM_HALVE(3) DRM_HALVE(4) DRM_HALVE(5)
+#undef DRM_HALVE
+    return v[0];
+}
+template <int NV>
+__device__ __forceinline__ int halving_index(int lane) {
+    constexpr int LG = NV >= 64 ? 6 : NV >= 32 ? 5 : NV >= 16 ? 4 : NV >= 8 ? 3 : NV >= 4 ? 2 : NV >= 2 ? 1 : 0;
+    int idx = 0;
+#pragma unroll
+    for (int j = 0; j < LG; ++j) idx |= ((lane >> j) & 1) << (LG - 1 - j);
+    return idx;
+}
+
+// Sum over the 64 lanes, on every lane, of each of NV per-lane values (independent butterflies: six
+// dependent levels whatever NV is).
+template <int NV>
+__device__ __forceinline__ void all_sum64(float (&v)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = group_sum<64>(v[i]);
+}
+
+// predicated 16-byte load (the zero is a prvalue on purpose: selecting between two lvalues would turn
+// into a select of ADDRESSES followed by a generic-address load)
+__device__ __forceinline__ float4 ld4(const float* p, bool on) {
+    if (on) return *reinterpret_cast<const float4*>(p);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int RW, int CP>
+__global__ __launch_bounds__(256) void k_skinny(const SkinnyLaunch L) {
+    constexpr int NV = RW * CP;
+    static_assert(NV >= 2 && NV <= 64 && (NV & (NV - 1)) == 0, "RW*CP must be a power of two in [2, 64]");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int pi = L.np - 1;
+    while (pi > 0 && (int)blockIdx.x < L.p[pi].wg_begin) --pi;
+    const SkinnyProblem& P = L.p[pi];
+    const int cg = blockIdx.x - P.wg_begin;            // column group of this workgroup
+    const int K = P.K;
+    const int kA = 4 * lane, kB = 256 + 4 * lane;
+    const bool vA = kA < K, vB = kB < K;
+    const int row0 = blockIdx.y * (4 * RW) + wave * RW;
+    const bool ln = P.ln_g != nullptr;
+    STAMP_DECL
+    STAMP();
+
+    // ---- every load of the kernel is issued here, before the first use
+    float x[RW][8];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float* xp = P.X + (int64_t)min(row0 + r, L.M - 1) * P.ldx;
+        const float4 a = ld4(xp + kA, vA), b = ld4(xp + kB, vB);
+        x[r][0] = a.x; x[r][1] = a.y; x[r][2] = a.z; x[r][3] = a.w;
+        x[r][4] = b.x; x[r][5] = b.y; x[r][6] = b.z; x[r][7] = b.w;
+    }
+    float g[8], e[8];
+    {
+        const float4 ga = ld4(P.ln_g + kA, ln && vA), gb = ld4(P.ln_g + kB, ln && vB);
+        const float4 ea = ld4(P.ln_b + kA, ln && vA), eb = ld4(P.ln_b + kB, ln && vB);
+        g[0] = ga.x; g[1] = ga.y; g[2] = ga.z; g[3] = ga.w; g[4] = gb.x; g[5] = gb.y; g[6] = gb.z; g[7] = gb.w;
+        e[0] = ea.x; e[1] = ea.y; e[2] = ea.z; e[3] = ea.w; e[4] = eb.x; e[5] = eb.y; e[6] = eb.z; e[7] = eb.w;
+    }
+    float w[CP][8];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        const int n = cg * CP + c;
+        const bool ok = n < P.N;
+        const float* wp = P.W + (int64_t)(ok ? n : 0) * P.ldw;
+        const float4 a = ld4(wp + kA, ok && vA), b = ld4(wp + kB, ok && vB);
+        w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w;
+        w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w;
+    }
+    // the output element this lane will hold after the reduction
+    const int idx = halving_index<NV>(lane);
+    const int m = row0 + idx / CP;
+    const int n = cg * CP + idx % CP;
+    const bool writer = lane < NV && m < L.M && n < P.N;
+    const float bias = (writer && P.bias != nullptr) ? P.bias[n] : 0.f;
+
+#ifdef DRM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+#endif
+    // ---- LayerNorm + SiLU of the input rows.  One pass: sums of (x - c) and (x - c)^2 with c the
+    // row's first element as a shift (keeps the variance free of cancellation), every row's two sums
+    // reduced together.
+    if (ln) {
+        float st[2 * RW];
+        float shift[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            shift[r] = __shfl(x[r][0], 0, 64);
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool on = i < 4 ? vA : vB;
+                const float d = on ? x[r][i] - shift[r] : 0.f;
+                s += d;
+                q = fmaf(d, d, q);
+            }
+            st[2 * r] = s; st[2 * r + 1] = q;
+        }
+        all_sum64<2 * RW>(st);
+        const float inv_k = 1.0f / (float)K;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float md = st[2 * r] * inv_k;                       // mean - shift
+            const float var = fmaxf(st[2 * r + 1] * inv_k - md * md, 0.f);
+            const float rstd = 1.0f / sqrtf(var + LN_EPS);
+            const float mean = shift[r] + md;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool on = i < 4 ? vA : vB;
+                x[r][i] = on ? silu_f((x[r][i] - mean) * rstd * g[i] + e[i]) : 0.f;
+            }
+        }
+    }
+
+    STAMP();
+    // ---- partial dot products over this lane's 8 k, then the wave-level K reduction
+    float acc[NV];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a = fmaf(x[r][i], w[c][i], a);
+            acc[r * CP + c] = a;
+        }
+    const float tot = halving_sum64<NV>(acc, lane);
+#ifdef DRM_STAMPS
+    if (tot == 12345.678f) return;   // make the stamp wait for the reduction
+    STAMP();
+    STAMP_FLUSH((unsigned long long)(1000 + RW * 10 + CP));
+#endif
+    if (writer) P.Y[(int64_t)m * P.ldy + n] = tot + bias;
+}
+
+}  // namespace drm

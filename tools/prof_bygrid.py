@@ -2,7 +2,7 @@
 import csv, glob, sys, collections
 d, frac = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 pat = sys.argv[3] if len(sys.argv) > 3 else ""
-f = sorted(glob.glob(d + "/*/*kernel_trace.csv"))[-1]
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 t0 = min(int(r["Start_Timestamp"]) for r in rows); t1 = max(int(r["End_Timestamp"]) for r in rows)
 cut = t1 - (t1 - t0) * frac
@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: [0, 0])
 for r in rows:
     if int(r["Start_Timestamp"]) < cut or pat not in r["Kernel_Name"]:
         continue
-    key = (r["Kernel_Name"].split("(")[0][-34:], r["Grid_Size_X"], r["Grid_Size_Y"], r["VGPR_Count"], r["LDS_Block_Size"])
+    key = (r["Kernel_Name"].split("(")[0][-44:], r["Grid_Size_X"], r["Grid_Size_Y"], r["VGPR_Count"], r["LDS_Block_Size"])
     a = agg[key]; a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a[1] += 1
 tot = sum(v[0] for v in agg.values())
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:

@@ -40,7 +40,7 @@ for r in rec:
 for kid, v in sorted(stats.items()):
     import numpy as np
     a = np.array(v)
-    print(f"kernel {kid:4d} n={len(v):4d}  gap_from_prev_stamp_end {np.median(a[:,0]):8.0f} ns | phases (loads, LN, mfma, lds-write, barrier): "
+    print(f"kernel {kid:4d} n={len(v):4d}  gap_from_prev_stamp_end {np.median(a[:,0]):8.0f} ns | phases: "
           + " ".join(f"{np.median(a[:, i]):7.0f}" for i in range(1, a.shape[1])))
 for kid, v in sorted(xccs.items()):
     print("kernel", kid, "xcc of block 0 over launches:", v[:48])
