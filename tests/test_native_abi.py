@@ -39,4 +39,4 @@ def test_argument_validation_without_gpu():
     import ctypes
     assert handle.drm_pack_imagine_bytes(ctypes.byref(d)) == 0
     d.K = 32
-    assert handle.drm_pack_imagine_bytes(ctypes.byref(d)) == 4 * ((4 * 512 + 512) * 1024 + 6 * 512)
+    assert handle.drm_pack_imagine_bytes(ctypes.byref(d)) == 4 * ((4 * 512 + 512) * 1024 + 6 * 512 + 6 * 3 * 512)
