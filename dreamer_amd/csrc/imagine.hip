@@ -207,7 +207,7 @@ struct ActorGatesArgs {
     int M, A;
     const float* expo; int64_t lde;          // (B, A)
     const int64_t* forced; int64_t ldf;      // (B) strided or nullptr
-    float log1m_eps, log_eps_over_a;
+    float one_m_eps, eps_over_a;             // 1 - unimix_eps, unimix_eps / A
     const float* gi_z; int64_t ldgi;         // (B, 3D)
     const float* gi_a;                       // (A, 3D)
     const float* b_ih;                       // (3D)
@@ -285,30 +285,27 @@ __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     // every group of AMAX lanes of every wave evaluates the policy (no broadcast of the action needed)
     const float NEG = -3.0e38f;
     const float lg = aon ? ((s_dot[0][la] + s_dot[1][la]) + (s_dot[2][la] + s_dot[3][la])) + hb : NEG;
+    // P_a = (1-eps) softmax(logits)_a + eps/A is the policy (exp of the normalised log_unimix);
+    // torch.multinomial draws argmax_a P_a / E_a.  The draw needs no logarithm; the log-probabilities
+    // are formed after the action's table rows have been requested.
     const float mx = group_max<AMAX>(lg);
-    const float lse = logf(group_sum<AMAX>(aon ? expf(lg - mx) : 0.f));
-    const float mixed = aon ? logaddexp_f((lg - mx - lse) + P.log1m_eps, P.log_eps_over_a) : NEG;
-    // Categorical(logits=mixed) normalises once more
-    const float mx2 = group_max<AMAX>(mixed);
-    const float lse2 = mx2 + logf(group_sum<AMAX>(aon ? expf(mixed - mx2) : 0.f));
-    const float logp = mixed - lse2;
-    // probs = softmax(logp); multinomial draws argmax(probs / E)
-    const float mx3 = group_max<AMAX>(aon ? logp : NEG);
-    const float pe = aon ? expf(logp - mx3) : 0.f;
-    const float prob = pe / group_sum<AMAX>(pe);
-    float score = aon ? prob / ex : -1.f;
+    const float pa = aon ? expf(lg - mx) : 0.f;
+    const float zsum = group_sum<AMAX>(pa);                       // every lane takes part in the exchange
+    const float Pa = aon ? fmaf(pa, P.one_m_eps / zsum, P.eps_over_a) : 0.f;
+    float score = aon ? Pa / ex : -1.f;
     int ai = la;
     group_argmax<AMAX>(score, ai);
     const int used = forced >= 0 ? (int)forced : ai;
-    if (tid < P.A && P.logp_out) P.logp_out[(int64_t)b * P.ldlp + tid] = logp;
-    if (tid == 0) {
-        P.a_used[(int64_t)b * P.ldau] = used;
-        if (P.a_sampled) P.a_sampled[(int64_t)b * P.ldas] = ai;
-    }
     STAMP();
     // ---- GRU cell with the action's rows of gi_a
     const float* ga = P.gi_a + (int64_t)used * 3 * D;
     const float2 ga_r = ld2(ga + i0, jn), ga_u = ld2(ga + D + i0, jn), ga_n = ld2(ga + 2 * D + i0, jn);
+    if (tid == 0) {
+        P.a_used[(int64_t)b * P.ldau] = used;
+        if (P.a_sampled) P.a_sampled[(int64_t)b * P.ldas] = ai;
+    }
+    const float ptot = group_sum<AMAX>(Pa);
+    if (P.logp_out && tid < P.A) P.logp_out[(int64_t)b * P.ldlp + tid] = logf(Pa) - logf(ptot);
     if (!jn) return;
     const float r0 = sigmoid_f(((gz_r.x + ga_r.x) + bi_r.x) + gh_r.x), r1 = sigmoid_f(((gz_r.y + ga_r.y) + bi_r.y) + gh_r.y);
     const float u0 = sigmoid_f(((gz_u.x + ga_u.x) + bi_u.x) + gh_u.x), u1 = sigmoid_f(((gz_u.y + ga_u.y) + bi_u.y) + gh_u.y);
@@ -850,7 +847,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                 a.head_w = w->actor.head_w; a.head_b = w->actor.head_b; a.M = M; a.A = d.A;
                 a.expo = io->expo_a + (size_t)t * B * d.A; a.lde = d.A;
                 a.forced = io->forced_actions ? io->forced_actions + t : nullptr; a.ldf = H;
-                a.log1m_eps = l1m; a.log_eps_over_a = lea;
+                a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_a = d.unimix_eps / (float)d.A;
                 a.gi_z = ws + wl.gi; a.ldgi = 3 * D; a.gi_a = pack + pl.gi_a; a.b_ih = w->gru_b_ih;
                 a.gh = ws + wl.gh; a.ldgh = 3 * D; a.h_prev = h_t; a.ldh = ldh; a.h_new = h_new; a.ldhn = (int64_t)H * D; a.D = D;
                 a.a_used = io->actions_out + t; a.ldau = H;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_skinny(const SkinnyLaunch L) {
         float shift[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            shift[r] = __shfl(x[r][0], 0, 64);
+            shift[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x[r][0])));
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -163,14 +163,12 @@ __global__ __launch_bounds__(256) void k_skinny(const SkinnyLaunch L) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const float md = st[2 * r] * inv_k;                       // mean - shift
-            const float var = fmaxf(st[2 * r + 1] * inv_k - md * md, 0.f);
-            const float rstd = 1.0f / sqrtf(var + LN_EPS);
+            const float var = fmaxf(fmaf(-md, md, st[2 * r + 1] * inv_k), 0.f);
+            const float rstd = __builtin_amdgcn_rsqf(var + LN_EPS);
             const float mean = shift[r] + md;
+            // lanes beyond K hold g = e = 0, so they come out as SiLU(0) = 0 without a select
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool on = i < 4 ? vA : vB;
-                x[r][i] = on ? silu_f((x[r][i] - mean) * rstd * g[i] + e[i]) : 0.f;
-            }
+            for (int i = 0; i < 8; ++i) x[r][i] = silu_f(fmaf((x[r][i] - mean) * rstd, g[i], e[i]));
         }
     }
 

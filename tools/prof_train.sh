@@ -1,0 +1,14 @@
+#!/bin/bash
+# kernel-trace stats of the training update: bash tools/prof_train.sh <name>
+set -e
+name=${1:-ptrain}
+root=$(pwd)
+out=$root/gpurun_out/$name
+rm -rf "$out"; mkdir -p "$out"
+cd /tmp
+export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$out" -o "$name" --output-format csv -- \
+    python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 --profile-steps 0 --train-steps 30 > "$out/bench.json" 2> "$out/err.txt"
+python3 "$root/tools/prof_window.py" "$out" 0.02 60 > "$out/stats.txt"
+find "$out" -name '*kernel_trace.csv' -delete
+cat "$out/stats.txt"

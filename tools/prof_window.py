@@ -1,7 +1,7 @@
 """Aggregate a rocprofv3 kernel trace over its last FRACTION of wall time (steady state)."""
 import csv, glob, sys, collections
 d, frac = sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
-f = sorted(glob.glob(d + "/*/*kernel_trace.csv"))[-1]
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 t0 = min(int(r["Start_Timestamp"]) for r in rows); t1 = max(int(r["End_Timestamp"]) for r in rows)
 cut = t1 - (t1 - t0) * frac
