@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
     }
 }
 
-static int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
+int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                       hipStream_t stream) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
     BigLaunch L{};

@@ -155,12 +155,16 @@ static inline int launch_stbwd(const ProblemSpec& spec, int M, int latents, cons
     return DRM_OK;
 }
 
+// large-row MFMA GEMM (defined next to its kernel in imagine.hip)
+int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
+               hipStream_t stream);
+
 // ---- few-row path ---------------------------------------------------------------------------------
 // Problems of one launch share their rows and the (RW, CP) shape; LayerNorm is per problem.
 constexpr int SKINNY_MAX_ROWS = 64;    // above this many rows the MFMA tiles are the better cut
 
 static inline bool skinny_ok(const ProblemSpec& s) {
-    return s.K <= 512 && s.tab == nullptr && s.add == nullptr && s.rowscale == nullptr;
+    return s.K <= 512 && s.tab == nullptr && s.rowscale == nullptr;
 }
 
 template <int RW>
@@ -202,7 +206,7 @@ static inline int launch_skinny(const ProblemSpec* specs, int np, int M, hipStre
         SkinnyProblem& p = L.p[i];
         p.X = specs[i].X; p.ldx = specs[i].ldx; p.ln_g = specs[i].ln_g; p.ln_b = specs[i].ln_b;
         p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.Y = specs[i].Y; p.ldy = specs[i].ldy;
-        p.N = specs[i].N; p.K = specs[i].K; p.wg_begin = wgs;
+        p.N = specs[i].N; p.K = specs[i].K; p.wg_begin = wgs; p.add = specs[i].add; p.ldadd = specs[i].ldadd;
         wgs += (specs[i].N + cp - 1) / cp;
     }
     L.np = np; L.M = M;

@@ -28,6 +28,7 @@ struct SkinnyProblem {
     float* Y; int64_t ldy;
     int N, K;
     int wg_begin;                              // first blockIdx.x of this problem
+    const float* add; int64_t ldadd;           // Y += add[m][n] or nullptr
 };
 
 struct SkinnyLaunch {
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) void k_skinny(const SkinnyLaunch L) {
     const int m = row0 + idx / CP;
     const int n = cg * CP + idx % CP;
     const bool writer = lane < NV && m < L.M && n < P.N;
-    const float bias = (writer && P.bias != nullptr) ? P.bias[n] : 0.f;
+    float bias = (writer && P.bias != nullptr) ? P.bias[n] : 0.f;
+    if (writer && P.add != nullptr) bias += P.add[(int64_t)m * P.ldadd + n];
 
 #ifdef DRM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,4 +1,13 @@
-// Observe (posterior) recurrence over a replayed (B, T) batch: three launches per time step.
+// Observe (posterior) recurrence over a replayed (B, T) batch.
+//
+// Few sequences (B <= 64, the training batch): two launches per time step.
+//   k_observe_gates : draw z_{t-1} from the previous step's posterior logits, episode-boundary reset, then
+//                     the GRU cell.  x_t = lin_b + sum_l lin_zT[z_l] + c a_tab[a] enters the cell only
+//                     through W_ih x_t, and z is one-hot, so gi is a sum of rows of the packed table
+//                     gz = lin_zT W_ih^T (plus c * ga[a], ga = a_tab W_ih^T): no matrix product.
+//   k_skinny        : posterior logits = e_part + W_fc_h h_t  and  gh_raw = W_hh h_t  (both read h_t)
+//   x_t itself (saved for the weight gradients) is formed for all steps at once after the loop.
+// More sequences: three launches per time step.
 //   k_observe_reset_x : episode-boundary reset, one-hot row gather of the GRU input x
 //   k_linear16<3,GRU> : gi = W_ih x on MFMA + gate combine with the precomputed W_hh h  -> h_t
 //   k_linear16<2,SAMPLE> (+ companion store problem): posterior logits = e_part + W_fc_h h_t, unimix,
@@ -79,6 +88,177 @@ __global__ __launch_bounds__(256) void k_observe_reset_x(const ResetArgs P) {
     if (jn1) { P.x[(int64_t)b * P.ldxo + i1] = xz1 + c * at1; P.h_in[(int64_t)b * P.ldhi + i1] = c * hp1; }
 }
 
+// ---- few-sequence path ---------------------------------------------------------------------------
+struct ObsGatesArgs {
+    // draw of z_{t-1} (post == nullptr at t = 0: z_prev0 is given)
+    const float* post; int64_t ldpost;        // (B, L*32) posterior logits of step t-1
+    const float* expo_z; int64_t ldez;        // (B, L*32) Exp(1) noise of that draw
+    float* y_out; int64_t ldy;                // (B, L*32) soft sample probabilities of step t-1
+    uint8_t* zidx_out; int64_t ldzo;          // (B, L)
+    float* z_dense; int64_t ldzd;             // (B, L*32) or nullptr
+    const uint8_t* z_prev0; int64_t ldz0;
+    float one_m_eps, eps_over_k;
+    // episode-boundary reset of step t
+    const float* c_prev; int64_t ldc;
+    const float* expo_reset; int64_t lder;    // (B, L*32)
+    const int64_t* a_prev; int64_t lda;
+    uint8_t* z_in_out; int64_t ldzi;          // (B, L) latents fed into step t
+    // GRU cell
+    const float* gz; const float* ga;         // (L*32, 3D), (A, 3D)
+    const float* b_ih; const float* b_hh;     // (3D); b_ih here = W_ih lin_b + b_ih (the packed gb)
+    const float* gh_raw; int64_t ldgh;        // (B, 3D) = W_hh h_{t-1}
+    const float* h_prev; int64_t ldh;
+    float* h_out; int64_t ldho;
+    float* h_in_out; int64_t ldhi;            // c * h_{t-1}
+    float* gates_out; int64_t ldgo;           // (B, 4D): r, u, n, gh_n
+    int D, L, do_step;                        // do_step == 0: only the draw (after the last step)
+};
+
+// grid (ceil(D / 32), B): workgroup = 32 hidden units of one sequence.  Every workgroup of a sequence
+// repeats the draw (1024 logits, four per thread) rather than wait for another workgroup.
+__global__ __launch_bounds__(256) void k_observe_gates(const ObsGatesArgs P) {
+    __shared__ uint8_t s_z[64];
+    __shared__ __attribute__((aligned(16))) float s_red[3][32][32];
+    __shared__ float s_gi[3][32];
+    const int b = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+    const int sub = tid & 7;
+    const int D = P.D;
+    const float c = P.do_step ? P.c_prev[(int64_t)b * P.ldc] : 1.f;
+    // operands of the gate arithmetic (threads 0..31), requested before anything else
+    const int j = slice * 32 + (tid & 31);
+    const bool gate_thread = P.do_step && tid < 32 && j < D;
+    float ghr = 0.f, ghu = 0.f, ghn = 0.f, bir = 0.f, biu = 0.f, bin_ = 0.f, gar = 0.f, gau = 0.f, gan = 0.f, hp = 0.f;
+    if (gate_thread) {
+        const float* gh = P.gh_raw + (int64_t)b * P.ldgh;
+        const float* ga = P.ga + (int64_t)P.a_prev[(int64_t)b * P.lda] * 3 * D;
+        ghr = gh[j] * c + P.b_hh[j]; ghu = gh[D + j] * c + P.b_hh[D + j]; ghn = gh[2 * D + j] * c + P.b_hh[2 * D + j];
+        bir = P.b_ih[j]; biu = P.b_ih[D + j]; bin_ = P.b_ih[2 * D + j];
+        gar = ga[j]; gau = ga[D + j]; gan = ga[2 * D + j];
+        hp = P.h_prev[(int64_t)b * P.ldh + j] * c;
+    }
+    for (int l = tid >> 3; l < P.L; l += 32) {
+        int zs;
+        if (P.post != nullptr) {
+            // y = softmax(log_unimix(post) - log E) = q / sum q with q_k = ((1-eps) softmax(post)_k + eps/K) / E_k
+            const float4 lg = *reinterpret_cast<const float4*>(P.post + (int64_t)b * P.ldpost + l * 32 + sub * 4);
+            const float4 ex = *reinterpret_cast<const float4*>(P.expo_z + (int64_t)b * P.ldez + l * 32 + sub * 4);
+            const float v[4] = {lg.x, lg.y, lg.z, lg.w};
+            const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+            const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            float pj[4], s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pj[i] = expf(v[i] - mx); s += pj[i]; }
+            const float scale = P.one_m_eps / group_sum<8>(s);
+            float q[4], qs = 0.f, best = -1.f;
+            int bi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                q[i] = fmaf(pj[i], scale, P.eps_over_k) / e[i];
+                qs += q[i];
+                if (q[i] > best) { best = q[i]; bi = sub * 4 + i; }
+            }
+            qs = group_sum<8>(qs);
+            group_argmax<8>(best, bi);
+            zs = bi;
+            if (slice == 0) {
+                const int k0 = sub * 4;
+                *reinterpret_cast<float4*>(P.y_out + (int64_t)b * P.ldy + l * 32 + k0) =
+                    make_float4(q[0] / qs, q[1] / qs, q[2] / qs, q[3] / qs);
+                if (sub == 0) P.zidx_out[(int64_t)b * P.ldzo + l] = (uint8_t)bi;
+                if (P.z_dense)
+                    *reinterpret_cast<float4*>(P.z_dense + (int64_t)b * P.ldzd + l * 32 + k0) =
+                        make_float4(bi == k0 ? 1.f : 0.f, bi == k0 + 1 ? 1.f : 0.f, bi == k0 + 2 ? 1.f : 0.f, bi == k0 + 3 ? 1.f : 0.f);
+            }
+        } else {
+            zs = P.z_prev0[(int64_t)b * P.ldz0 + l];
+        }
+        if (P.do_step && c == 0.f) {
+            // fresh uniform one-hot (lib/world_model.py:57-61): argmax softmax(1/K - log E) = the class with the smallest E
+            const float4 ex = *reinterpret_cast<const float4*>(P.expo_reset + (int64_t)b * P.lder + l * 32 + sub * 4);
+            const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+            float best = -3.0e38f;
+            int bi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (-e[i] > best) { best = -e[i]; bi = sub * 4 + i; }
+            group_argmax<8>(best, bi);
+            zs = bi;
+        }
+        if (sub == 0) {
+            s_z[l] = (uint8_t)zs;
+            if (slice == 0 && P.do_step) P.z_in_out[(int64_t)b * P.ldzi + l] = (uint8_t)zs;
+        }
+    }
+    if (!P.do_step) return;
+    __syncthreads();
+    // gi slice = sum over latents of table rows: thread (latent slot, 4 columns), three gates
+    {
+        const int ls = tid >> 3, c4 = sub * 4;
+        const int jj = slice * 32 + c4;
+        float4 a[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jj < D) {
+            for (int l = ls; l < P.L; l += 32) {
+                const float* row = P.gz + (int64_t)(l * 32 + s_z[l]) * 3 * D + jj;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float4 u = *reinterpret_cast<const float4*>(row + g * D);
+                    a[g].x += u.x; a[g].y += u.y; a[g].z += u.z; a[g].w += u.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) *reinterpret_cast<float4*>(&s_red[g][ls][c4]) = a[g];
+    }
+    __syncthreads();
+    if (tid < 96) {
+        const int g = tid >> 5, jl = tid & 31;
+        float a = 0.f;
+        const int live = P.L < 32 ? P.L : 32;
+        for (int i = 0; i < live; ++i) a += s_red[g][i][jl];
+        s_gi[g][jl] = a;
+    }
+    __syncthreads();
+    if (!gate_thread) return;
+    const int jl = tid & 31;
+    const float rr = sigmoid_f(((s_gi[0][jl] + c * gar) + bir) + ghr);
+    const float uu = sigmoid_f(((s_gi[1][jl] + c * gau) + biu) + ghu);
+    const float nn = tanhf(((s_gi[2][jl] + c * gan) + bin_) + rr * ghn);
+    P.h_out[(int64_t)b * P.ldho + j] = (1.0f - uu) * nn + uu * hp;
+    P.h_in_out[(int64_t)b * P.ldhi + j] = hp;
+    float* go = P.gates_out + (int64_t)b * P.ldgo;
+    go[j] = rr; go[D + j] = uu; go[2 * D + j] = nn; go[3 * D + j] = ghn;
+}
+
+// x[r] = lin_b + sum_l lin_zT[l*32 + z_in[r, l]] + c[r] * a_tab[a[r]] for all r = (b, t) rows at once
+// (the GRU input, needed only by the weight gradients); one workgroup per row, D <= 512.
+struct XBulkArgs {
+    const uint8_t* z_in; const int64_t* a_prev; const float* c_prev;
+    const float* lin_zT; const float* lin_b; const float* a_tab;
+    float* x; int D, L;
+};
+__global__ __launch_bounds__(256) void k_observe_x_bulk(const XBulkArgs P) {
+    __shared__ uint8_t s_z[64];
+    const int64_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < P.L) s_z[tid] = P.z_in[r * P.L + tid];
+    const float c = P.c_prev[r];
+    const int a = (int)P.a_prev[r];
+    __syncthreads();
+    for (int i = tid; i < P.D; i += 256) {
+        float acc = P.lin_b[i];
+        for (int l0 = 0; l0 < P.L; l0 += 8) {
+            float u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = (l0 + q < P.L) ? P.lin_zT[(int64_t)((l0 + q) * 32 + s_z[l0 + q]) * P.D + i] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += u[q];
+        }
+        P.x[r * P.D + i] = acc + c * P.a_tab[(int64_t)a * P.D + i];
+    }
+}
+
 // defined in imagine.hip's translation unit as well; both are file-local
 __global__ __launch_bounds__(256) void k_transpose_cols_o(const float* __restrict__ W, int64_t ldw, int col0, int ncols,
                                                            int nrows, float* __restrict__ out) {
@@ -117,12 +297,16 @@ static int check_observe_dims(const drm_dims& d) {
     return DRM_OK;
 }
 
-struct ObsPack { size_t lin_zT, a_tab, total; };
+struct ObsPack { size_t lin_zT, a_tab, gz, ga, gb, total; };
 static ObsPack obs_pack_layout(const drm_dims& d) {
     ObsPack p{};
+    auto up4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
     p.lin_zT = 0;
     p.a_tab = (size_t)d.L * d.K * d.D;
-    p.total = (p.a_tab + (size_t)d.A * d.D + 3) & ~(size_t)3;
+    p.gz = up4(p.a_tab + (size_t)d.A * d.D);
+    p.ga = p.gz + (size_t)d.L * d.K * 3 * d.D;
+    p.gb = up4(p.ga + (size_t)d.A * 3 * d.D);
+    p.total = up4(p.gb + (size_t)3 * d.D);
     return p;
 }
 
@@ -146,6 +330,56 @@ static int observe_enqueue(const drm_observe_weights* w, const drm_observe_io* i
     const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
     const int64_t TD = (int64_t)T * D, TL = (int64_t)T * L, TLK = (int64_t)T * LK;
 
+    if (B <= SKINNY_MAX_ROWS) {
+        {   // gh_raw for step 0 from h0
+            ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D};
+            if (int rc = launch_skinny(&p, 1, B, s)) return rc;
+        }
+        for (int t = 0; t <= T; ++t) {
+            ObsGatesArgs a{};
+            a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
+            a.D = D; a.L = L; a.do_step = t < T ? 1 : 0;
+            if (t > 0) {
+                a.post = io->post_out + (size_t)(t - 1) * LK; a.ldpost = TLK;
+                a.expo_z = io->expo_z + (size_t)(t - 1) * B * LK; a.ldez = LK;
+                a.y_out = io->y_out + (size_t)(t - 1) * LK; a.ldy = TLK;
+                a.zidx_out = io->zidx_out + (size_t)(t - 1) * L; a.ldzo = TL;
+                a.z_dense = io->z_out ? io->z_out + (size_t)(t - 1) * LK : nullptr; a.ldzd = TLK;
+            } else {
+                a.z_prev0 = io->zidx0; a.ldz0 = L;
+            }
+            if (t < T) {
+                a.c_prev = io->c_prev + t; a.ldc = T;
+                a.expo_reset = io->expo_reset + (size_t)t * B * LK; a.lder = LK;
+                a.a_prev = io->a_prev + t; a.lda = T;
+                a.z_in_out = io->zidx_in_out + (size_t)t * L; a.ldzi = TL;
+                a.gz = w->pack + pl.gz; a.ga = w->pack + pl.ga; a.b_ih = w->pack + pl.gb; a.b_hh = w->gru_b_hh;
+                a.gh_raw = ghraw; a.ldgh = 3 * D;
+                a.h_prev = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D; a.ldh = t == 0 ? D : TD;
+                a.h_out = io->h_out + (size_t)t * D; a.ldho = TD;
+                a.h_in_out = io->h_in_out + (size_t)t * D; a.ldhi = TD;
+                a.gates_out = io->gates_out + (size_t)t * 4 * D; a.ldgo = (int64_t)T * 4 * D;
+            }
+            {
+                ProfScope prof(PC_GRU, s, (double)B * (40.0 * LK + 3.0 * D * (L + 8)),
+                               4.0 * (double)B * (3.0 * LK + 3.0 * D * (L + 4)));
+                k_observe_gates<<<dim3(t < T ? (D + 31) / 32 : 1, B), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+            if (t == T) break;
+            float* h_t = io->h_out + (size_t)t * D;
+            ProblemSpec p[2] = {
+                {h_t, TD, nullptr, nullptr, w->fc_w_h, w->ld_fc, nullptr, nullptr, 0, io->post_out + (size_t)t * LK, TLK, LK, D},
+                {h_t, TD, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D}};
+            p[0].add = io->e_part + (size_t)t * LK; p[0].ldadd = TLK;
+            if (int rc = launch_skinny(p, t + 1 < T ? 2 : 1, B, s)) return rc;
+        }
+        XBulkArgs x{io->zidx_in_out, io->a_prev, io->c_prev, w->pack + pl.lin_zT, w->lin_b, w->pack + pl.a_tab, io->x_out, D, L};
+        ProfScope prof(PC_GATHER, s, (double)B * T * D * (L + 2), 4.0 * (double)B * T * D * (L + 3));
+        k_observe_x_bulk<<<dim3((unsigned)((int64_t)B * T)), dim3(256), 0, s>>>(x);
+        DRM_LAUNCH_CHECK();
+        return DRM_OK;
+    }
     {   // gh_raw for step 0 from h0
         ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D};
         if (int rc = launch_store(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
@@ -217,14 +451,28 @@ extern "C" int drm_pack_observe(const drm_observe_weights* w, float* pack_out, s
     DRM_REQUIRE(w->lin_w && w->a_emb, DRM_EINVAL, "null weight");
     hipStream_t s = (hipStream_t)stream;
     const int LK = d.L * d.K;
-    ProfScope prof(PC_PACK, s, 2.0 * d.A * d.D * d.E, 8.0 * (double)LK * d.D);
-    k_transpose_cols_o<<<dim3((LK + 31) / 32, (d.D + 31) / 32), dim3(256), 0, s>>>(w->lin_w, LK + d.E, 0, LK, d.D,
-                                                                                  pack_out + pl.lin_zT);
-    DRM_LAUNCH_CHECK();
-    k_action_table_o<<<dim3((d.D + 255) / 256, d.A), dim3(256), 0, s>>>(w->lin_w, LK + d.E, LK, d.E, w->a_emb, d.A, d.D,
-                                                                         pack_out + pl.a_tab);
-    DRM_LAUNCH_CHECK();
-    return DRM_OK;
+    {
+        ProfScope prof(PC_PACK, s, 2.0 * d.A * d.D * d.E, 8.0 * (double)LK * d.D);
+        k_transpose_cols_o<<<dim3((LK + 31) / 32, (d.D + 31) / 32), dim3(256), 0, s>>>(w->lin_w, LK + d.E, 0, LK, d.D,
+                                                                                      pack_out + pl.lin_zT);
+        DRM_LAUNCH_CHECK();
+        k_action_table_o<<<dim3((d.D + 255) / 256, d.A), dim3(256), 0, s>>>(w->lin_w, LK + d.E, LK, d.E, w->a_emb, d.A, d.D,
+                                                                             pack_out + pl.a_tab);
+        DRM_LAUNCH_CHECK();
+    }
+    // gz = lin_zT W_ih^T (one row of GRU input pre-activations per (latent, class)), ga = a_tab W_ih^T
+    DRM_REQUIRE(w->gru_w_ih, DRM_EINVAL, "null weight");
+    ProblemSpec gz{pack_out + pl.lin_zT, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
+                   pack_out + pl.gz, 3 * d.D, 3 * d.D, d.D};
+    if (int rc = launch_big(&gz, 1, LK, nullptr, 0, 0, 0, s)) return rc;
+    ProblemSpec ga{pack_out + pl.a_tab, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
+                   pack_out + pl.ga, 3 * d.D, 3 * d.D, d.D};
+    if (d.A <= SKINNY_MAX_ROWS) { if (int rc = launch_skinny(&ga, 1, d.A, s)) return rc; }
+    else if (int rc = launch_store(&ga, 1, d.A, nullptr, 0, 0, 0, s)) return rc;
+    // gb = W_ih lin_b + b_ih: the constant part of gi
+    DRM_REQUIRE(w->lin_b && w->gru_b_ih && aligned16(w->lin_b), DRM_EINVAL, "null or misaligned lin_b / b_ih");
+    ProblemSpec gb{w->lin_b, d.D, nullptr, nullptr, w->gru_w_ih, d.D, w->gru_b_ih, nullptr, 0, pack_out + pl.gb, 3 * d.D, 3 * d.D, d.D};
+    return launch_skinny(&gb, 1, 1, s);
 }
 
 extern "C" size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, int32_t T) {
