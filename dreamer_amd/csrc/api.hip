@@ -50,9 +50,9 @@ extern "C" int drm_prof_enable(int enable) {
 }
 
 extern "C" const char* drm_prof_class_name(int cls) {
-    static const char* names[DRM_PROF_CLASSES] = {"k_linear16<1,store>", "k_linear16<3,gru>", "k_linear16<2,sample>",
-                                                  "k_actor_head_x", "k_scalar_heads", "k_critic_value", "k_lambda_return",
-                                                  "k_seq_gather", "k_sample_st", "pack", "k_linear_big", "elementwise"};
+    static const char* names[DRM_PROF_CLASSES] = {"linear", "gru", "linear+sample",
+                                                  "actor_head", "k_scalar_heads", "k_critic_value", "k_lambda_return",
+                                                  "k_seq_gather", "sample", "pack", "k_linear_big", "elementwise"};
     return (cls >= 0 && cls < DRM_PROF_CLASSES) ? names[cls] : "";
 }
 

@@ -32,4 +32,5 @@ pmc imagine4096 FETCH_SIZE --workload imagine4096 --steps 3 --warmup 1
 pmc imagine4096 WRITE_SIZE --workload imagine4096 --steps 3 --warmup 1
 pmc imagine16 FETCH_SIZE --workload imagine16 --steps 10 --warmup 2
 pmc imagine16 WRITE_SIZE --workload imagine16 --steps 10 --warmup 2
+python3 "$root/tools/pmc_to_json.py" "$out" "$out/pmc.json"
 echo done
