@@ -149,8 +149,11 @@ def measure_train(device, world, rank, steps, warmup, fence):
     def step():
         return learner.update(buf.sample(cfg.batch_size, want_f32=True))
 
-    for _ in range(warmup):
+    for i in range(warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            progress("first training update done")
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -169,6 +172,11 @@ def measure_train(device, world, rank, steps, warmup, fence):
             "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}
 
 
+def progress(msg):
+    """One line on stderr per phase (stdout carries only the JSON line)."""
+    print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,12 +191,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hook for a one-GPU box: every rank on device 0, collectives over gloo (exercises the
+    # multi-process control flow; the measured numbers mean nothing then)
+    rehearsal = os.environ.get("DRM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from dreamer_amd import _native as N
     from dreamer_amd.imagine import ImagineEngine
@@ -223,6 +239,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(out["lam_returns"]).all()
+    progress(f"imagination block: {elapsed / args.steps * 1e3:.3f} ms per block on this rank")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -274,7 +291,9 @@ def main():
 
     train = None
     if args.train_steps > 0:
+        progress("training updates: building the learner, warm-up (includes the convolution kernel search)")
         train = measure_train(device, world, rank, args.train_steps, 6, fence)
+        progress(f"training updates: {train['ms_per_update']:.2f} ms per update")
 
     if rank == 0:
         value = world * B * H * args.steps / elapsed

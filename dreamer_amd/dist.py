@@ -84,12 +84,21 @@ class FlatGrads:
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
-    """Give every rank rank-``src``'s parameters and buffers (identical replicas at start)."""
+    """Give every rank rank-``src``'s parameters and buffers (identical replicas at start): one
+    collective per dtype on a flat copy."""
     if world_size() == 1:
         return
     with torch.no_grad():
+        by_dtype = {}
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src)
+            by_dtype.setdefault(t.dtype, []).append(t.data)
+        for tensors in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            dist.broadcast(flat, src=src)
+            o = 0
+            for t in tensors:
+                t.copy_(flat[o:o + t.numel()].view_as(t))
+                o += t.numel()
 
 
 def gather_flat(x: torch.Tensor) -> torch.Tensor:
