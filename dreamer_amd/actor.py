@@ -35,11 +35,11 @@ class EMAPercentileScale(nn.Module):
         if self.gather is not None:
             x = self.gather(x)
         lo = torch.quantile(x, 0.05)
-        hi = torch.maximum(torch.quantile(x, 0.95), lo + x.new_tensor(1e-8))
+        hi = torch.maximum(torch.quantile(x, 0.95), lo + 1e-8)
         if self.training:
             self.p05.mul_(self.decay).add_((1.0 - self.decay) * lo)
             self.p95.mul_(self.decay).add_((1.0 - self.decay) * hi)
-        return torch.maximum(self.p95 - self.p05, x.new_tensor(self.min_scale))
+        return (self.p95 - self.p05).clamp_min(self.min_scale)
 
 
 class Actor(nn.Module):
@@ -63,7 +63,15 @@ class Actor(nn.Module):
 
     def loss(self, model_states: WorldModelState, actions: torch.Tensor, returns: torch.Tensor,
              values: torch.Tensor) -> torch.Tensor:
-        dist = self(model_states)
-        scale = self.ret_scale.update_get_S(returns.detach())
+        return self.loss_with_scale(model_states, actions, returns, values, self.ret_scale.update_get_S(returns.detach()))
+
+    def loss_with_scale(self, model_states: WorldModelState, actions: torch.Tensor, returns: torch.Tensor,
+                        values: torch.Tensor, scale: torch.Tensor, validate: bool = False) -> torch.Tensor:
+        """The loss of lib/actor.py:108-125 for a return scale S that has already been updated.  The
+        distribution is built without argument validation (its checks read results back to the host,
+        which a recorded graph cannot do); the arithmetic is the same."""
+        x = state_features(model_states)
+        logits = self.head(self.mlp(x.reshape(-1, x.size(-1)))).reshape(*x.shape[:-1], -1)
+        dist = torch.distributions.Categorical(logits=log_unimix(logits, self.unimix_eps, dim=-1), validate_args=validate)
         advantage = ((returns - values) / scale).detach()
         return -(advantage * dist.log_prob(actions)).mean() - self.entropy_scale * dist.entropy().mean()

@@ -122,7 +122,7 @@ class ObserveScanFn(torch.autograd.Function):
         g_post = torch.zeros_like(post) if g_post is None else g_post.contiguous()
         # time-parallel pieces of the unimix / log-softmax backward
         ls = F.log_softmax(post, dim=-1)
-        w_mix = torch.exp(ls + log1m - torch.logaddexp(ls + log1m, ls.new_tensor(floor)))
+        w_mix = torch.exp(ls + log1m - torch.logaddexp(ls + log1m, torch.full((), floor, dtype=ls.dtype, device=ls.device)))
         p_soft = ls.exp()
         fcT, ihT, hhT = fc_w_h.t().contiguous(), w_ih.t().contiguous(), w_hh.t().contiguous()
         d_gi = torch.empty(B, T, 3 * D, device=dev, dtype=h.dtype)

@@ -35,9 +35,70 @@ from .utils import log_episode_video, log_wm_imagination_video, log_wm_reconstru
 from .world_model import WorldModel, WorldModelState
 
 
-def _adam(params, lr, eps):
+def _adam(params, lr, eps, capturable=False):
     params = list(params)
-    return torch.optim.Adam(params, lr=lr, eps=eps, fused=params[0].is_cuda)
+    return torch.optim.Adam(params, lr=lr, eps=eps, fused=params[0].is_cuda, capturable=capturable and params[0].is_cuda)
+
+
+class _GraphedUpdate:
+    """One small-model update (loss -> backward -> [gradient all-reduce] -> clip -> Adam -> post) replayed
+    as two HIP graphs around the all-reduce.
+
+    The actor and critic updates are a few hundred tiny kernels on B*H rows; run eagerly they cost the
+    host's launch time (~1.7 ms each), replayed from a graph they cost their GPU time.  Inputs are
+    copied into fixed buffers; the loss and every intermediate live in the graph's memory pool.
+    """
+
+    def __init__(self, loss_fn, grads: D.FlatGrads, clip: float, optim: torch.optim.Optimizer, post=None):
+        self.loss_fn, self.grads, self.clip, self.optim, self.post = loss_fn, grads, clip, optim, post
+        self.static = None
+        self.g_loss = self.g_step = None
+        self.loss_out = None
+
+    def run(self, *inputs: torch.Tensor) -> torch.Tensor:
+        if self.g_loss is None:
+            self._capture(inputs)
+        else:
+            for dst, src in zip(self.static, inputs):
+                dst.copy_(src)
+        self.g_loss.replay()
+        self.grads.sync()
+        self.g_step.replay()
+        return self.loss_out
+
+    def _capture(self, inputs) -> None:
+        self.static = [t.detach().clone() for t in inputs]
+        params = [p for p in self.grads.module.parameters() if p.requires_grad]
+        # the parameters' gradient-accumulation nodes were made on the main stream by the eager updates;
+        # autograd notes the change of stream once per node, which is expected here
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # settle allocator / autograd state on a side stream: loss + backward only
+            for _ in range(2):
+                self.grads.zero()
+                self.loss_fn(*self.static).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        self.g_loss = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_loss):
+            self.grads.zero()
+            self.loss_out = self.loss_fn(*self.static)
+            self.loss_out.backward()
+        self._capture_step(params)
+
+    def _capture_step(self, params) -> None:
+        self.g_step = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_step):
+            nn.utils.clip_grad_norm_(params, self.clip)
+            self.optim.step()
+            if self.post is not None:
+                self.post()
+
+    def step_only(self) -> None:
+        """clip -> Adam -> post for gradients that are already in the flat buffer (and reduced)."""
+        if self.g_step is None:
+            self._capture_step([p for p in self.grads.params])
+        self.g_step.replay()
 
 
 class Learner:
@@ -62,10 +123,22 @@ class Learner:
         for m in (self.world_model, self.actor, self.critic):
             D.broadcast_module(m)
         self.actor.ret_scale.gather = D.gather_flat if D.world_size() > 1 else None
-        self.optim_world_model = _adam(self.world_model.parameters(), cfg.world_model_lr, cfg.world_model_adam_eps)
-        self.optim_actor = _adam(self.actor.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps)
-        self.optim_critic = _adam(self.critic.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps)
+        self.optim_world_model = _adam(self.world_model.parameters(), cfg.world_model_lr, cfg.world_model_adam_eps,
+                                       capturable=torch.device(dev).type == "cuda")
+        on_gpu = torch.device(dev).type == "cuda"
+        self.optim_actor = _adam(self.actor.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
+        self.optim_critic = _adam(self.critic.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
         self.g_wm, self.g_actor, self.g_critic = D.FlatGrads(self.world_model), D.FlatGrads(self.actor), D.FlatGrads(self.critic)
+        # actor / critic updates replayed from HIP graphs after a few eager ones (DRM_NO_UPDATE_GRAPHS=1: always eager)
+        self.graph_updates = on_gpu and os.environ.get("DRM_NO_UPDATE_GRAPHS", "0") != "1"
+        self.eager_updates = 0
+        self._wm_graph = _GraphedUpdate(None, self.g_wm, cfg.world_model_grad_clip, self.optim_world_model)
+        self._critic_graph = _GraphedUpdate(
+            lambda h, z, ret: self.critic.loss(model_states=WorldModelState(h=h, z=z), returns=ret),
+            self.g_critic, cfg.actor_critic_grad_clip, self.optim_critic, post=self.critic.update_slow)
+        self._actor_graph = _GraphedUpdate(
+            lambda h, z, act, ret, val, scale: self.actor.loss_with_scale(WorldModelState(h=h, z=z), act, ret, val, scale),
+            self.g_actor, cfg.actor_critic_grad_clip, self.optim_actor)
 
     def update(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         cfg = self.cfg
@@ -77,14 +150,25 @@ class Learner:
         self.g_wm.zero()
         wm_loss.backward()
         self.g_wm.sync()
-        nn.utils.clip_grad_norm_(self.world_model.parameters(), cfg.world_model_grad_clip)
-        self.optim_world_model.step()
+        if self.graph_updates and self.eager_updates >= 3:
+            self._wm_graph.step_only()
+        else:
+            nn.utils.clip_grad_norm_(self.world_model.parameters(), cfg.world_model_grad_clip)
+            self.optim_world_model.step()
         # ---- imagination from the last posterior states, with the updated world model ----
         start: WorldModelState = wm_info["state"]
         im = imagine(self.world_model, self.actor, self.critic,
                      WorldModelState(h=start.h.detach(), z=start.z.detach()), cfg.imagination_horizon, cfg.gamma, cfg.lam)
         Hs = WorldModelState(h=im["h"], z=im["z"])
         returns, values, actions = im["lam_returns"], im["values"], im["actions"]
+        if self.graph_updates and self.eager_updates >= 3:
+            critic_loss = self._critic_graph.run(Hs.h, Hs.z, returns)
+            scale = self.actor.ret_scale.update_get_S(returns.detach())   # rank-global percentiles (may all-gather)
+            actor_loss = self._actor_graph.run(Hs.h, Hs.z, actions, returns, values, scale.reshape(()))
+            return {"world_model_loss": wm_loss.detach(), "actor_loss": actor_loss.detach().clone(),
+                    "critic_loss": critic_loss.detach().clone(), "pred_loss": wm_info["pred_loss"].detach(),
+                    "dyn_loss": wm_info["dyn_loss"].detach(), "rep_loss": wm_info["rep_loss"].detach(), "imagination": im}
+        self.eager_updates += 1
         # ---- critic ----
         critic_loss = self.critic.loss(model_states=Hs, returns=returns)
         self.g_critic.zero()

@@ -26,7 +26,8 @@ def log_unimix(logits: torch.Tensor, eps: float, dim: int = -1) -> torch.Tensor:
     """log((1 - eps) * softmax(logits) + eps / K), computed in log space."""
     k = logits.size(dim)
     shifted = F.log_softmax(logits, dim=dim) + math.log1p(-float(eps))
-    floor = logits.new_tensor(math.log(float(eps)) - math.log(float(k)))
+    # a fill kernel rather than new_tensor(): no host-to-device copy, so the op can be recorded into a graph
+    floor = torch.full((), math.log(float(eps)) - math.log(float(k)), dtype=logits.dtype, device=logits.device)
     return torch.logaddexp(shifted, floor)
 
 
