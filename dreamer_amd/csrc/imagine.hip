@@ -191,6 +191,80 @@ __global__ __launch_bounds__(256) void k_actor_head_x(const ActorHeadArgs P) {
     if (jn1) P.x[(int64_t)b * P.ldxo + i1] = xz1 + t1;
 }
 
+// The same for any width (M, D up to 4096): features and columns are walked in strides of 256.
+__global__ __launch_bounds__(256) void k_actor_head_wide(const ActorHeadArgs P) {
+    __shared__ float s4[4];
+    __shared__ uint8_t s_z[MAX_LATENTS];
+    __shared__ float s_dot[4][32];
+    __shared__ int s_a;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const float* pre = P.pre + (int64_t)b * P.ldp;
+    if (tid < P.latents) s_z[tid] = P.zidx[(int64_t)b * P.ldz + tid];
+    float s = 0.f;
+    for (int i = tid; i < P.M; i += 256) s += pre[i];
+    const float mean = block_sum_256(s, s4) / (float)P.M;
+    float qv = 0.f;
+    for (int i = tid; i < P.M; i += 256) { const float d = pre[i] - mean; qv += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum_256(qv, s4) / (float)P.M + LN_EPS);
+    float dot[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) dot[a] = 0.f;
+    for (int i = tid; i < P.M; i += 256) {
+        const float act = silu_f((pre[i] - mean) * rstd * P.ln_g[i] + P.ln_b[i]);
+#pragma unroll
+        for (int a = 0; a < 32; ++a)
+            if (a < P.A) dot[a] = fmaf(act, P.head_w[(int64_t)a * P.M + i], dot[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+        const float d = group_sum<64>(dot[a]);
+        if (lane == 0) s_dot[wave][a] = d;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool on = lane < P.A;
+        const float NEG = -3.0e38f;
+        const int la = on ? lane : 0;
+        const float ex = on ? P.expo[(int64_t)b * P.lde + la] : 1.f;
+        const float lg = on ? ((s_dot[0][la] + s_dot[1][la]) + (s_dot[2][la] + s_dot[3][la])) + P.head_b[la] : NEG;
+        const float mx = group_max<64>(lg);
+        const float lse = logf(group_sum<64>(on ? expf(lg - mx) : 0.f));
+        const float mixed = on ? logaddexp_f((lg - mx - lse) + P.log1m_eps, P.log_eps_over_a) : NEG;
+        const float mx2 = group_max<64>(mixed);
+        const float lse2 = mx2 + logf(group_sum<64>(on ? expf(mixed - mx2) : 0.f));
+        const float logp = mixed - lse2;
+        const float mx3 = group_max<64>(on ? logp : NEG);
+        const float pe = on ? expf(logp - mx3) : 0.f;
+        const float prob = pe / group_sum<64>(pe);
+        float score = on ? prob / ex : -1.f;
+        int ai = lane;
+        group_argmax<64>(score, ai);
+        if (on && P.logp_out) P.logp_out[(int64_t)b * P.ldlp + lane] = logp;
+        if (lane == 0) {
+            int used = ai;
+            if (P.forced) used = (int)P.forced[(int64_t)b * P.ldf];
+            s_a = used;
+            P.a_used[(int64_t)b * P.ldau] = used;
+            if (P.a_sampled) P.a_sampled[(int64_t)b * P.ldas] = ai;
+        }
+    }
+    __syncthreads();
+    const int act = s_a;
+    for (int jcol = tid; jcol < P.D; jcol += 256) {
+        float acc = P.lin_b[jcol];
+        for (int l0 = 0; l0 < P.latents; l0 += 8) {
+            float u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                u[q] = (l0 + q < P.latents) ? P.lin_zT[(int64_t)((l0 + q) * P.classes + s_z[l0 + q]) * P.D + jcol] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += u[q];
+        }
+        P.x[(int64_t)b * P.ldxo + jcol] = acc + P.a_tab[(int64_t)act * P.D + jcol];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // few-row path: actor head + action draw + GRU cell, one workgroup per trajectory.
 //   act = SiLU(LN(pre));  logits = head(act);  logp = normalise(log_unimix(logits));  a = argmax(softmax(logp) / E)
@@ -598,17 +672,21 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
 
 static int launch_ln_silu(const float* X, int64_t ldx, const float* g, const float* e, float* Y, int64_t ldy, int M, int K,
                           hipStream_t stream) {
-    DRM_REQUIRE(K <= 512 && K % 4 == 0, DRM_ENOTSUP, "LayerNorm width %d", K);
+    DRM_REQUIRE(K <= 4096 && K % 4 == 0, DRM_ENOTSUP, "LayerNorm width %d", K);
     ProfScope prof(PC_ELEMENTWISE, stream, 12.0 * M * K, 8.0 * M * K);
-    k_ln_silu_rows<<<dim3((M + 3) / 4), dim3(256), 0, stream>>>(X, ldx, g, e, Y, ldy, M, K);
+    const dim3 grid((M + 3) / 4), block(256);
+    if (K <= 512) k_ln_silu_rows<2><<<grid, block, 0, stream>>>(X, ldx, g, e, Y, ldy, M, K);
+    else if (K <= 1024) k_ln_silu_rows<4><<<grid, block, 0, stream>>>(X, ldx, g, e, Y, ldy, M, K);
+    else if (K <= 2048) k_ln_silu_rows<8><<<grid, block, 0, stream>>>(X, ldx, g, e, Y, ldy, M, K);
+    else k_ln_silu_rows<16><<<grid, block, 0, stream>>>(X, ldx, g, e, Y, ldy, M, K);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
 
 static int check_dims(const drm_dims& d) {
     DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
-    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0 && d.D <= 512 && d.M <= 512, DRM_ENOTSUP,
-                "D=%d and M=%d must be multiples of 32, at most 512", d.D, d.M);
+    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.M >= 32 && d.M % 32 == 0 && d.D <= 4096 && d.M <= 4096, DRM_ENOTSUP,
+                "D=%d and M=%d must be multiples of 32, at most 4096", d.D, d.M);
     DRM_REQUIRE(d.L >= 1 && d.L <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", d.L, MAX_LATENTS);
     DRM_REQUIRE(d.A >= 1 && d.A <= 32, DRM_ENOTSUP, "actions=%d (max 32)", d.A);
     DRM_REQUIRE(d.NB >= 1 && d.NB <= 256, DRM_ENOTSUP, "buckets=%d (max 256)", d.NB);
@@ -650,12 +728,13 @@ static WsLayout ws_layout(const drm_dims& d, int B, int H) {
     const size_t rows = (size_t)B * H;
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) w.head[i][j] = take(rows * d.M);
     w.critic_logits = take(rows * 256);
-    if (B >= BIG_MIN_ROWS) {
+    const bool wide = d.D > 512 || d.M > 512;
+    if (B >= BIG_MIN_ROWS || wide) {
         w.gi = take((size_t)B * 3 * d.D);
         w.logits = take((size_t)B * d.L * d.K);
         for (int i = 0; i < 3; ++i) w.act[i] = take(rows * d.M);
     }
-    if (B <= SKINNY_MAX_ROWS) {
+    if (B <= SKINNY_MAX_ROWS && !wide) {
         w.gi = take((size_t)B * 3 * d.D);
         w.logits = take((size_t)B * d.L * d.K);
         w.a1h = take((size_t)B * d.M);
@@ -725,7 +804,8 @@ extern "C" int drm_pack_imagine(const drm_imagine_weights* w, float* pack_out, s
     // gi_a[a] = W_ih a_tab[a]: the action's share of the GRU input product, one row per action
     ProblemSpec g{pack_out + pl.a_tab, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
                   pack_out + pl.gi_a, 3 * d.D, 3 * d.D, d.D};
-    return launch_skinny(&g, 1, d.A, s);
+    if (d.D <= 512) return launch_skinny(&g, 1, d.A, s);
+    return launch_big(&g, 1, d.A, nullptr, 0, 0, 0, s);
 }
 
 extern "C" size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H) {
@@ -778,10 +858,11 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const float l1m = (float)log1p(-(double)d.unimix_eps);
     const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
     const float lea = (float)(log((double)d.unimix_eps) - log((double)d.A));
-    const bool big = B >= BIG_MIN_ROWS;
+    const bool wide = D > 512 || M > 512;                // beyond the register-resident small-row kernels
+    const bool big = B >= BIG_MIN_ROWS || wide;
     float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
 
-    const bool few = B <= SKINNY_MAX_ROWS;
+    const bool few = B <= SKINNY_MAX_ROWS && !wide;
     if (few) {
         // ---- few-row path: every layer is cut into ~256 workgroups; the draw of z and the one-hot
         // tables it selects (actor layer 1, GRU input) share one launch
@@ -917,7 +998,8 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             a.logp_out = io->actor_logp_out ? io->actor_logp_out + (size_t)t * d.A : nullptr; a.ldlp = (int64_t)H * d.A;
             ProfScope prof(PC_ACTOR_HEAD, s, 2.0 * B * M * d.A + (double)B * D * (L + 1),
                            4.0 * ((double)B * M + (double)d.A * M + (double)B * D * (L + 2)));
-            if (d.A <= 8 && L <= 32) k_actor_head_x<8, 32><<<dim3(B), dim3(256), 0, s>>>(a);
+            if (wide) k_actor_head_wide<<<dim3(B), dim3(256), 0, s>>>(a);
+            else if (d.A <= 8 && L <= 32) k_actor_head_x<8, 32><<<dim3(B), dim3(256), 0, s>>>(a);
             else if (L <= 32) k_actor_head_x<32, 32><<<dim3(B), dim3(256), 0, s>>>(a);
             else k_actor_head_x<32, 64><<<dim3(B), dim3(256), 0, s>>>(a);
             DRM_LAUNCH_CHECK();

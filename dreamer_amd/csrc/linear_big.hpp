@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
 }
 
 // ---- elementwise companions of the large-row path ---------------------------------------------------
-// Y = SiLU(LayerNorm(X row)); one wave per row, K <= 512 kept in registers (two-pass statistics).
+// Y = SiLU(LayerNorm(X row)); one wave per row, the row (K <= 256 * NV) kept in registers (two-pass statistics).
+template <int NV>
 __global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ X, int64_t ldx, const float* __restrict__ g,
                                                        const float* __restrict__ e, float* __restrict__ Y, int64_t ldy,
                                                        int M, int K) {
@@ -215,10 +216,10 @@ __global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ 
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
     const float* x = X + (int64_t)row * ldx;
-    float4 v[2];
+    float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int k = (i * 64 + lane) * 4;
         v[i] = k < K ? *reinterpret_cast<const float4*>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ 
     const float mean = group_sum<64>(s) / (float)K;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int k = (i * 64 + lane) * 4;
         if (k < K) {
             const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ 
     }
     const float rstd = 1.0f / sqrtf(group_sum<64>(q) / (float)K + LN_EPS);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int k = (i * 64 + lane) * 4;
         if (k < K) {
             const float4 gg = *reinterpret_cast<const float4*>(g + k);

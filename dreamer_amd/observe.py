@@ -157,7 +157,8 @@ class ObserveScanFn(torch.autograd.Function):
 
 def observe_scan(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state):
     """Returns (h (B,T,D), z (B,T,L,K), post_logits (B,T,L,K), last WorldModelState)."""
-    if not e_part.is_cuda:
+    if not e_part.is_cuda or state.h.size(-1) > 512:
+        # host tensors, or a recurrent width beyond what the scan kernels are built for (D <= 512)
         return _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state)
     from . import _native as N
     from .world_model import WorldModelState

@@ -134,10 +134,10 @@ typedef struct drm_mlp {
 } drm_mlp;
 
 typedef struct drm_dims {
-    int32_t D;   /* recurrent width (hidden_size): multiple of 32, <= 512 */
+    int32_t D;   /* recurrent width (hidden_size): multiple of 32, <= 4096 (observe scan: <= 512) */
     int32_t L;   /* latents */
     int32_t K;   /* classes per latent: must be 32 */
-    int32_t M;   /* mlp_hidden_units: multiple of 32, <= 512 */
+    int32_t M;   /* mlp_hidden_units: multiple of 32, <= 4096 */
     int32_t A;   /* actions (<= 32) */
     int32_t E;   /* action embedding width (64) */
     int32_t NB;  /* critic buckets (<= 256) */

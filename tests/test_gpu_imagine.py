@@ -76,6 +76,27 @@ def test_teacher_forced_vs_oracle(B, H, layers):
     assert torch.equal(out["actions_sampled"].cpu()[clear_a], ref["actions"][clear_a])
 
 
+@pytest.mark.parametrize("B,H,D,M", [(6, 3, 1024, 768), (20, 2, 640, 1024), (260, 2, 1024, 544)])
+def test_wide_models_teacher_forced_vs_oracle(B, H, D, M):
+    """Widths beyond 512 (BASELINE config 5 scales the recurrent width) run on the large-row kernels for any batch."""
+    d = dict(DIMS["small"], D=D, M=M, L=6, A=5)
+    salt = 500 + B
+    wm, actor, critic = build_models(d, salt)
+    ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    with torch.no_grad():
+        ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
+    ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea.to(DEV), "z": ez.to(DEV)},
+                  forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV), want_prior_logits=True)
+    torch.cuda.synchronize()
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+        assert rel_err(out[key].cpu(), ref[key]) < TOL, key
+
+
 def test_large_batch_properties():
     """B = 4096 trajectories (BASELINE config 3): rows are independent, so any slice of the batch
     must reproduce, bit for bit, what the same rows give when run alone."""
