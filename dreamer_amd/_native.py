@@ -65,7 +65,7 @@ class drm_imagine_io(C.Structure):
                 ("prior_logits_out", C.c_void_p), ("rewards_out", C.c_void_p), ("conts_out", C.c_void_p),
                 ("values_out", C.c_void_p), ("v_last_out", C.c_void_p), ("lam_returns_out", C.c_void_p),
                 ("gamma", C.c_double), ("lam", C.c_double), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t), ("use_graph", C.c_int32)]
+                ("workspace_bytes", C.c_size_t), ("use_graph", C.c_int32), ("precision", C.c_int32)]
 
 
 class drm_observe_weights(C.Structure):
@@ -104,6 +104,7 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_onehot_to_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_fused_linear_f32": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
+    "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_pack_imagine_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
     "drm_pack_imagine": (C.c_int, [C.POINTER(drm_imagine_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
@@ -215,8 +216,9 @@ def onehot_to_index(z: torch.Tensor) -> torch.Tensor:
     return idx
 
 
-def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None):
-    """Y = f(x) @ w[:, :K]^T + bias (+ one-hot table rows).  ``w`` may be wider than K (``w_cols`` = K)."""
+def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None, bf16: bool = False):
+    """Y = f(x) @ w[:, :K]^T + bias (+ one-hot table rows).  ``w`` may be wider than K (``w_cols`` = K).
+    ``bf16``: bf16 matrix inputs with fp32 accumulation (no LayerNorm prologue)."""
     require_cuda(x, w)
     M, K = x.shape
     N = w.shape[0]
@@ -235,7 +237,10 @@ def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int =
         a.latents, a.classes = zidx.shape[1], classes
     a.Y, a.ldy = y.data_ptr(), y.stride(0)
     a.M, a.N, a.K = M, N, K
-    check(lib().drm_fused_linear_f32(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_f32")
+    if bf16:
+        check(lib().drm_fused_linear_bf16(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_bf16")
+    else:
+        check(lib().drm_fused_linear_f32(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_f32")
     return y
 
 

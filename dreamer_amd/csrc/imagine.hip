@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
 }
 
 int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
-                      hipStream_t stream) {
+               hipStream_t stream, int precision) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
     BigLaunch L{};
     int tiles = 0;
@@ -665,7 +665,8 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
-    k_linear_big<<<dim3(tiles, (M + BIG_BM - 1) / BIG_BM), dim3(256), 0, stream>>>(L);
+    if (precision == 1) k_linear_big_bf16<<<dim3(tiles, (M + BIG_BM - 1) / BIG_BM), dim3(256), 0, stream>>>(L);
+    else k_linear_big<<<dim3(tiles, (M + BIG_BM - 1) / BIG_BM), dim3(256), 0, stream>>>(L);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -808,6 +809,14 @@ extern "C" int drm_pack_imagine(const drm_imagine_weights* w, float* pack_out, s
     return launch_big(&g, 1, d.A, nullptr, 0, 0, 0, s);
 }
 
+extern "C" int drm_fused_linear_bf16(const drm_linear_args* a, drm_stream_t stream) {
+    DRM_REQUIRE(a, DRM_EINVAL, "null args");
+    DRM_REQUIRE(a->M >= 1 && a->ln_gamma == nullptr, DRM_EINVAL, "M=%d; the bf16 product takes activated inputs", a->M);
+    DRM_REQUIRE(!a->table || (a->classes >= 1 && a->latents >= 1), DRM_EINVAL, "bad gather shape");
+    ProblemSpec s{a->X, a->ldx, nullptr, nullptr, a->W, a->ldw, a->bias, a->table, a->ldt, a->Y, a->ldy, a->N, a->K};
+    return launch_big(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream, 1);
+}
+
 extern "C" size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H) {
     if (!dims || check_dims(*dims) != DRM_OK || B < 1 || H < 1) return 0;
     return ws_layout(*dims, B, H).total * sizeof(float);
@@ -827,14 +836,14 @@ extern "C" int drm_fused_linear_f32(const drm_linear_args* a, drm_stream_t strea
 // LayerNorm + SiLU on load; the large-row kernels take activated inputs, so the activation is a pass
 // of its own into `act[i]` first.
 static int run_linear(ProblemSpec* p, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes, bool big,
-                      float* const* act, int act_ld, hipStream_t s) {
+                      float* const* act, int act_ld, hipStream_t s, int precision = 0) {
     if (!big) return launch_store(p, np, M, zidx, ldz, latents, classes, s);
     for (int i = 0; i < np; ++i) {
         if (p[i].ln_g == nullptr) continue;
         if (int rc = launch_ln_silu(p[i].X, p[i].ldx, p[i].ln_g, p[i].ln_b, act[i], act_ld, M, p[i].K, s)) return rc;
         p[i].X = act[i]; p[i].ldx = act_ld; p[i].ln_g = nullptr; p[i].ln_b = nullptr;
     }
-    return launch_big(p, np, M, zidx, ldz, latents, classes, s);
+    return launch_big(p, np, M, zidx, ldz, latents, classes, s, precision);
 }
 
 static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
@@ -858,6 +867,8 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const float l1m = (float)log1p(-(double)d.unimix_eps);
     const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
     const float lea = (float)(log((double)d.unimix_eps) - log((double)d.A));
+    DRM_REQUIRE(io->precision == 0 || io->precision == 1, DRM_EINVAL, "precision=%d", io->precision);
+    const int prec = io->precision;
     const bool wide = D > 512 || M > 512;                // beyond the register-resident small-row kernels
     const bool big = B >= BIG_MIN_ROWS || wide;
     float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
@@ -964,7 +975,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     // gh for step 0
     {
         ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D};
-        if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, big, act, M, s)) return rc;
+        if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, big, act, M, s, prec)) return rc;
     }
     for (int t = 0; t < H; ++t) {
         const float* h_t = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D;
@@ -978,7 +989,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                                         ws + wl.a_pre[0], M, M, D};
             else p = ProblemSpec{ws + wl.a_pre[(i - 1) & 1], M, w->actor.ln_g[i - 1], w->actor.ln_b[i - 1], w->actor.w[i], M,
                                  w->actor.b[i], nullptr, 0, ws + wl.a_pre[i & 1], M, M, M};
-            if (int rc = run_linear(&p, 1, B, z_t, ldz, L, d.K, big, act, M, s)) return rc;
+            if (int rc = run_linear(&p, 1, B, z_t, ldz, L, d.K, big, act, M, s, prec)) return rc;
         }
         // actor head, action draw, GRU input row
         {
@@ -1012,7 +1023,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             if (int rc = launch_gru(p, B, G, s)) return rc;
         } else {
             ProblemSpec p{ws + wl.x, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, ws + wl.gi, 3 * D, 3 * D, D};
-            if (int rc = launch_big(&p, 1, B, nullptr, 0, 0, 0, s)) return rc;
+            if (int rc = launch_big(&p, 1, B, nullptr, 0, 0, 0, s, prec)) return rc;
             ProfScope prof(PC_ELEMENTWISE, s, 20.0 * B * D, 4.0 * 8.0 * B * D);
             k_gru_gates<<<dim3((unsigned)(((int64_t)B * D + 255) / 256)), dim3(256), 0, s>>>(
                 ws + wl.gi, 3 * D, w->gru_b_ih, ws + wl.gh, 3 * D, h_t, ldh, h_new, (int64_t)H * D, B, D);
@@ -1023,19 +1034,19 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             ProblemSpec p[2] = {
                 {h_new, (int64_t)H * D, nullptr, nullptr, w->dyn.w[0], D, w->dyn.b[0], nullptr, 0, ws + wl.d_pre[0], M, M, D},
                 {h_new, (int64_t)H * D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D}};
-            if (int rc = run_linear(p, t + 1 < H ? 2 : 1, B, nullptr, 0, 0, 0, big, act, M, s)) return rc;
+            if (int rc = run_linear(p, t + 1 < H ? 2 : 1, B, nullptr, 0, 0, 0, big, act, M, s, prec)) return rc;
         }
         for (int i = 1; i < w->dyn.n_layers; ++i) {
             ProblemSpec p{ws + wl.d_pre[(i - 1) & 1], M, w->dyn.ln_g[i - 1], w->dyn.ln_b[i - 1], w->dyn.w[i], M, w->dyn.b[i],
                           nullptr, 0, ws + wl.d_pre[i & 1], M, M, M};
-            if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, big, act, M, s)) return rc;
+            if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, big, act, M, s, prec)) return rc;
         }
         // dyn head + unimix + Gumbel-argmax draw of z_{t+1}
         if (big) {
             const int last = w->dyn.n_layers - 1;
             ProblemSpec p{ws + wl.d_pre[last & 1], M, w->dyn.ln_g[last], w->dyn.ln_b[last], w->dyn.head_w, M, w->dyn.head_b,
                           nullptr, 0, ws + wl.logits, LK, LK, M};
-            if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, true, act, M, s)) return rc;
+            if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, true, act, M, s, prec)) return rc;
             SampleRowsArgs a{};
             a.logits = ws + wl.logits; a.ldlg = LK; a.expo = io->expo_z + (size_t)t * B * LK; a.lde = LK;
             a.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.ldf = (int64_t)H * L;
@@ -1088,7 +1099,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             }
         }
         if (np == 0) continue;
-        if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s)) return rc;
+        if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s, prec)) return rc;
     }
     {
         ScalarHeadsArgs a{};

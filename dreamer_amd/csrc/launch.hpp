@@ -157,7 +157,7 @@ static inline int launch_stbwd(const ProblemSpec& spec, int M, int latents, cons
 
 // large-row MFMA GEMM (defined next to its kernel in imagine.hip)
 int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
-               hipStream_t stream);
+               hipStream_t stream, int precision = 0);
 
 // ---- few-row path ---------------------------------------------------------------------------------
 // Problems of one launch share their rows and the (RW, CP) shape; LayerNorm is per problem.

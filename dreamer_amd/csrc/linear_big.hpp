@@ -206,6 +206,167 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
     }
 }
 
+// ---- bf16 matrix inputs, fp32 accumulation (v_mfma_f32_32x32x16_bf16) ------------------------------
+// Same tiling and epilogue as k_linear_big.  Operands stay fp32 in memory and are rounded to bf16
+// (round to nearest even) on their way into LDS; a lane's fragment is 8 consecutive k = one 16-byte LDS
+// read, and a K-step of 32 is two MFMAs per 32x32 accumulator instead of sixteen.  LDS image: bf16
+// [row][k], row stride 40 elements (80 bytes): the 16 lanes a ds_read_b128 serves together start 20
+// banks apart and cover all 64 banks once.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BIG_LDH = 40;
+
+__global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
+    __shared__ __attribute__((aligned(16))) float smem[BIG_BM * (BIG_BN + 4)];   // 64 x 132 floats >= the bf16 stages
+    __bf16 (*sA)[BIG_BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BM][BIG_LDH]>(smem);
+    __bf16 (*sB)[BIG_BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BN][BIG_LDH]>(reinterpret_cast<__bf16*>(smem) + 2 * BIG_BM * BIG_LDH);
+
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    int lin = blockIdx.y * nbx + blockIdx.x;
+    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+    const int bx = lin % nbx, by = lin / nbx;
+
+    int pi = L.np - 1;
+    while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
+    const BigProblem& P = L.p[pi];
+    const int n0 = (bx - P.tile_begin) * BIG_BN;
+    const int m0 = by * BIG_BM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = P.K;
+
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    const float* xa[2];
+    const float* wb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+
+    const int nk = K / BIG_BK;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a00, a01, b00, b01, b02, b03;
+    float4 a10, a11, b10, b11, b12, b13;
+#define BIGH_LOAD(S, ko)                                                    \
+    a##S##0 = *reinterpret_cast<const float4*>(xa[0] + (ko));               \
+    a##S##1 = *reinterpret_cast<const float4*>(xa[1] + (ko));               \
+    b##S##0 = *reinterpret_cast<const float4*>(wb[0] + (ko));               \
+    b##S##1 = *reinterpret_cast<const float4*>(wb[1] + (ko));               \
+    b##S##2 = *reinterpret_cast<const float4*>(wb[2] + (ko));               \
+    b##S##3 = *reinterpret_cast<const float4*>(wb[3] + (ko));
+#define BIGH_PUT(dst, v)                                                    \
+    {                                                                       \
+        bf16x4 h;                                                           \
+        h[0] = (__bf16)(v).x; h[1] = (__bf16)(v).y; h[2] = (__bf16)(v).z; h[3] = (__bf16)(v).w; \
+        *reinterpret_cast<bf16x4*>(dst) = h;                                \
+    }
+#define BIGH_STORE(S, buf)                                                  \
+    BIGH_PUT(&sA[buf][srow][skq], a##S##0)                                  \
+    BIGH_PUT(&sA[buf][srow + 32][skq], a##S##1)                             \
+    BIGH_PUT(&sB[buf][srow][skq], b##S##0)                                  \
+    BIGH_PUT(&sB[buf][srow + 32][skq], b##S##1)                             \
+    BIGH_PUT(&sB[buf][srow + 64][skq], b##S##2)                             \
+    BIGH_PUT(&sB[buf][srow + 96][skq], b##S##3)
+#define BIGH_STEP(buf)                                                                                  \
+    {                                                                                                   \
+        const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(&sA[buf][wm * 32 + li][lh * 8]);            \
+        const bf16x8 fb00 = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + li][lh * 8]);           \
+        const bf16x8 fb10 = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + 32 + li][lh * 8]);      \
+        const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(&sA[buf][wm * 32 + li][16 + lh * 8]);       \
+        const bf16x8 fb01 = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + li][16 + lh * 8]);      \
+        const bf16x8 fb11 = *reinterpret_cast<const bf16x8*>(&sB[buf][wn * 64 + 32 + li][16 + lh * 8]); \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb00, acc0, 0, 0, 0);                       \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb10, acc1, 0, 0, 0);                       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb01, acc0, 0, 0, 0);                       \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb11, acc1, 0, 0, 0);                       \
+    }
+    BIGH_LOAD(0, 0)
+    a10 = a11 = b10 = b11 = b12 = b13 = zero4;
+    if (nk > 1) { BIGH_LOAD(1, BIG_BK) }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    for (int ks = 0; ks < nk; ks += 2) {
+        BIGH_STORE(0, 0)
+        __syncthreads();
+        if (ks + 2 < nk) { BIGH_LOAD(0, (ks + 2) * BIG_BK) }
+        BIGH_STEP(0)
+        if (ks + 1 < nk) {
+            BIGH_STORE(1, 1)
+            __syncthreads();
+            if (ks + 3 < nk) { BIGH_LOAD(1, (ks + 3) * BIG_BK) }
+            BIGH_STEP(1)
+        }
+    }
+#undef BIGH_LOAD
+#undef BIGH_PUT
+#undef BIGH_STORE
+#undef BIGH_STEP
+
+    // ---- epilogue (as k_linear_big): tile through LDS, + bias, + one-hot table rows, 16-byte stores
+    __syncthreads();
+    float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = acc0[i];
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const int n = n0 + c4;
+    if (n >= P.N) return;
+    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) {
+        bias.x = P.bias[n];
+        if (n + 1 < P.N) bias.y = P.bias[n + 1];
+        if (n + 2 < P.N) bias.z = P.bias[n + 2];
+        if (n + 3 < P.N) bias.w = P.bias[n + 3];
+    }
+    for (int r = tid >> 5; r < BIG_BM; r += 8) {
+        const int m = m0 + r;
+        if (m >= L.M) break;
+        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
+        if (P.tab != nullptr) {
+            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
+            if (vec) {
+                for (int l = 0; l < L.latents; l += 8) {
+                    float4 u[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ll = min(l + j, L.latents - 1);
+                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
+                }
+            } else {
+                for (int l = 0; l < L.latents; ++l) {
+                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
+                    y.x += tb[0];
+                    if (n + 1 < P.N) y.y += tb[1];
+                    if (n + 2 < P.N) y.z += tb[2];
+                    if (n + 3 < P.N) y.w += tb[3];
+                }
+            }
+        }
+        float* out = P.Y + (int64_t)m * P.ldy + n;
+        if (vec) {
+            *reinterpret_cast<float4*>(out) = y;
+        } else {
+            out[0] = y.x;
+            if (n + 1 < P.N) out[1] = y.y;
+            if (n + 2 < P.N) out[2] = y.z;
+            if (n + 3 < P.N) out[3] = y.w;
+        }
+    }
+}
+
 // ---- elementwise companions of the large-row path ---------------------------------------------------
 // Y = SiLU(LayerNorm(X row)); one wave per row, the row (K <= 256 * NV) kept in registers (two-pass statistics).
 template <int NV>

@@ -113,11 +113,12 @@ class ImagineEngine:
             noise: Optional[Dict[str, torch.Tensor]] = None, forced_actions: Optional[torch.Tensor] = None,
             forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
             want_prior_logits: bool = False, want_sampled: bool = False, start_zidx: Optional[torch.Tensor] = None,
-            repack: bool = True, persistent: bool = False) -> Dict[str, torch.Tensor]:
+            repack: bool = True, persistent: bool = False, precision: str = "f32") -> Dict[str, torch.Tensor]:
         """Run the block.  With ``persistent=True`` all inputs are staged into, and all outputs
         returned as, buffers that live as long as the engine (overwritten by the next call with the
         same shape); every device address is then the same from call to call and the native side
-        replays the block as one recorded hipGraph."""
+        replays the block as one recorded hipGraph.  ``precision="bf16"``: the matrix products of the
+        large-row path take bf16 inputs (fp32 accumulation, everything else fp32)."""
         d, dev = self.dims, self.device
         B, H = start.h.shape[0], int(horizon)
         if repack:
@@ -164,6 +165,7 @@ class ImagineEngine:
         io.gamma, io.lam = float(gamma), float(lam)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         io.use_graph = 1 if (persistent and forced_actions is None and forced_zidx is None) else 0
+        io.precision = {"f32": 0, "bf16": 1}[precision]
         w = self._weights()
         N.check(N.lib().drm_imagine_block_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_imagine_block_f32")
         return out

@@ -116,6 +116,10 @@ typedef struct drm_linear_args {
     int32_t M, N, K;
 } drm_linear_args;
 int drm_fused_linear_f32(const drm_linear_args* args, drm_stream_t stream);
+/* The same product with bf16 matrix inputs and fp32 accumulation (operands stay fp32 in memory and are
+ * rounded on load; v_mfma_f32_32x32x16_bf16).  No LayerNorm prologue (ln_gamma must be NULL); any M.
+ * Results agree with the fp32 form to about 1e-2 relative (the bf16 tolerance of the rollout). */
+int drm_fused_linear_bf16(const drm_linear_args* args, drm_stream_t stream);
 
 /* ---- imagination block: lib/trainer.py:176-224 ----------------------------------------------
  * actor -> sample action -> WorldModel.step(prior) for H steps, then reward / continue heads,
@@ -195,6 +199,9 @@ typedef struct drm_imagine_io {
     int32_t use_graph;             /* != 0: record the launches of this call into a hipGraph the first
                                       time this exact (weights, io) argument pair is seen and replay the
                                       graph afterwards (callers keep every buffer at a fixed address) */
+    int32_t precision;             /* 0: fp32 everywhere.  1: the matrix products of the large-row path
+                                      (B >= 256 or widths > 512) take bf16 inputs with fp32 accumulation;
+                                      LayerNorm, gates, sampling and the lambda-return stay fp32 */
 } drm_imagine_io;
 
 size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H);

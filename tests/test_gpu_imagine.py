@@ -97,6 +97,34 @@ def test_wide_models_teacher_forced_vs_oracle(B, H, D, M):
         assert rel_err(out[key].cpu(), ref[key]) < TOL, key
 
 
+def test_bf16_matrix_inputs_within_bf16_tolerance():
+    """Large-row path with bf16 matrix inputs (fp32 accumulation), teacher-forced along the oracle's
+    trajectory: states, rewards, values and lambda-returns within the bf16 tolerance of 1e-2."""
+    d = dict(DIMS["small"], D=128, M=128, L=8, A=5)
+    B, H, salt = 300, 4, 77
+    wm, actor, critic = build_models(d, salt)
+    ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    with torch.no_grad():
+        ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
+    ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
+    kw = dict(noise={"a": ea.to(DEV), "z": ez.to(DEV)}, forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV),
+              want_prior_logits=True)
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, precision="bf16", **kw)
+    exact = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, **kw)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+        err = rel_err(out[key].cpu(), ref[key])
+        worst = max(worst, err)
+        assert err < 1e-2, (key, err)
+        assert rel_err(exact[key].cpu(), ref[key]) < TOL, key
+    assert worst > 1e-5   # the reduced-precision products really ran
+
+
 def test_large_batch_properties():
     """B = 4096 trajectories (BASELINE config 3): rows are independent, so any slice of the batch
     must reproduce, bit for bit, what the same rows give when run alone."""

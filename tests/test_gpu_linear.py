@@ -58,3 +58,20 @@ def test_linear_rejects_bad_shapes():
     w = torch.zeros(8, 48, device=DEV)
     with pytest.raises(N.NativeError):
         N.fused_linear(x, w)   # K not a multiple of 32
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (4096, 512, 512), (1000, 1100, 1536), (37, 40, 96)])
+def test_bf16_input_product_matches_rounded_reference(M, N, K):
+    """bf16 matrix inputs, fp32 accumulation: equal to the fp64 product of the bf16-rounded operands to fp32
+    accumulation error, and to the fp32 product within the bf16 tolerance (1e-2)."""
+    from dreamer_amd import _native as N_
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    y = N_.fused_linear(x.cuda(), w.cuda(), b.cuda(), bf16=True).cpu()
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    ref_rounded = (xr @ wr.T + b.double()).float()
+    ref_f32 = (x.double() @ w.double().T + b.double()).float()
+    assert float((y - ref_rounded).abs().max() / ref_rounded.abs().max()) < 2e-5
+    assert float((y - ref_f32).abs().max() / ref_f32.abs().max()) < 1e-2
