@@ -661,7 +661,7 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
         tiles += (q.N + BIG_BN - 1) / BIG_BN;
         const double n = q.N, k = q.K, m = M;
         fl += 2.0 * m * n * k + (q.tab ? (double)latents * m * n : 0.0);
-        by += 4.0 * (m * k + n * k + n + m * n) + (q.tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
+        by += 4.0 * (m * k + n * k + n + m * n) + (q.tab ? 4.0 * latents * classes * n + (double)latents * m : 0.0);
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);

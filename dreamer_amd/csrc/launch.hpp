@@ -48,7 +48,7 @@ static inline int launch_store(const ProblemSpec* specs, int np, int M, const ui
     for (int i = 0; i < np; ++i) {
         const double n = specs[i].N, k = specs[i].K, m = M;
         fl += 2.0 * m * n * k + (specs[i].tab ? (double)latents * m * n : 0.0);
-        by += 4.0 * (m * k + n * k + n + m * n) + (specs[i].tab ? 4.0 * latents * m * n + (double)latents * m : 0.0);
+        by += 4.0 * (m * k + n * k + n + m * n) + (specs[i].tab ? 4.0 * latents * classes * n + (double)latents * m : 0.0);
     }
     DRM_REQUIRE(latents <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", latents, MAX_LATENTS);
     int kmax = 0;

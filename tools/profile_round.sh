@@ -12,6 +12,8 @@ export TMPDIR=/tmp
 
 stats() {  # name, bench args...
     local name=$1; shift
+    # the same command without the profiler first: its JSON line is the one to quote (a kernel trace slows short kernels)
+    timeout -k 10 300 python3 "$root/bench.py" --no-cpu-baseline --train-steps 0 "$@" > "$out/$name.clean.bench.json" 2> /dev/null
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/$name" -o "$name" --output-format csv -- \
         python3 "$root/bench.py" --no-cpu-baseline --train-steps 0 "$@" > "$out/$name.bench.json" 2> "$out/$name.err"
     python3 "$root/tools/prof_summary.py" "$out/$name" 30 > "$out/$name.stats.txt"
@@ -32,5 +34,6 @@ pmc imagine4096 FETCH_SIZE --workload imagine4096 --steps 3 --warmup 1
 pmc imagine4096 WRITE_SIZE --workload imagine4096 --steps 3 --warmup 1
 pmc imagine16 FETCH_SIZE --workload imagine16 --steps 10 --warmup 2
 pmc imagine16 WRITE_SIZE --workload imagine16 --steps 10 --warmup 2
+stats imagine4096_bf16 --workload imagine4096_bf16 --steps 20 --warmup 3
 python3 "$root/tools/pmc_to_json.py" "$out" "$out/pmc.json"
 echo done
