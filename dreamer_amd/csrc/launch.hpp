@@ -219,4 +219,61 @@ static inline int launch_skinny(const ProblemSpec* specs, int np, int M, hipStre
     return DRM_OK;
 }
 
+// K up to 1536 without LayerNorm; `G` != nullptr: one problem with the GRU-backward epilogue (N = G->D)
+template <int RW, int EPI>
+static inline void skinny_deep_dispatch(int cp, int kc, dim3 grid, hipStream_t stream, const SkinnyLaunch& L, const SkinnyGruBwd& G) {
+#define DRM_DEEP(CPV, KCV) k_skinny_deep<RW, CPV, KCV, EPI><<<grid, dim3(256), 0, stream>>>(L, G)
+    if (cp == 2) { if (kc == 1) DRM_DEEP(2, 1); else if (kc == 2) DRM_DEEP(2, 2); else DRM_DEEP(2, 3); }
+    else { if (kc == 1) DRM_DEEP(4, 1); else if (kc == 2) DRM_DEEP(4, 2); else DRM_DEEP(4, 3); }
+#undef DRM_DEEP
+}
+
+static inline bool skinny_deep_ok(const ProblemSpec& s) {
+    return s.K <= 1536 && s.ln_g == nullptr && s.tab == nullptr && s.rowscale == nullptr;
+}
+
+static inline int launch_skinny_deep(const ProblemSpec* specs, int np, int M, hipStream_t stream, const SkinnyGruBwd* G = nullptr) {
+    DRM_REQUIRE(np >= 1 && np <= SKINNY_MAX_PROBLEMS && M >= 1 && (G == nullptr || np == 1), DRM_EINVAL, "np=%d M=%d", np, M);
+    SkinnyLaunch L{};
+    int ntot = 0, kmax = 0;
+    double fl = 0, by = 0;
+    for (int i = 0; i < np; ++i) {
+        if (int rc = check_problem(specs[i])) return rc;
+        DRM_REQUIRE(skinny_deep_ok(specs[i]), DRM_ENOTSUP, "problem %d does not fit the few-row kernel", i);
+        ntot += specs[i].N;
+        kmax = specs[i].K > kmax ? specs[i].K : kmax;
+        const double n = specs[i].N, k = specs[i].K, m = M;
+        fl += 2.0 * m * n * k;
+        by += 4.0 * (m * k + n * k + n + m * n);
+    }
+    DRM_REQUIRE(G == nullptr || specs[0].N == G->D, DRM_EINVAL, "GRU backward epilogue needs N = D");
+    const int rw = skinny_rw(M, false);
+    const int tiles_m = (M + 4 * rw - 1) / (4 * rw);
+    const int cp = (int64_t)tiles_m * ((ntot + 1) / 2) > 384 ? 4 : 2;
+    const int kc = (kmax + 511) / 512;
+    int wgs = 0;
+    for (int i = 0; i < np; ++i) {
+        SkinnyProblem& p = L.p[i];
+        p.X = specs[i].X; p.ldx = specs[i].ldx; p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias;
+        p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.wg_begin = wgs;
+        p.add = specs[i].add; p.ldadd = specs[i].ldadd;
+        wgs += (specs[i].N + cp - 1) / cp;
+    }
+    L.np = np; L.M = M;
+    ProfScope prof(G ? PC_GRU : PC_LINEAR, stream, fl + (G ? 30.0 * M * G->D : 0.0), by + (G ? 56.0 * M * G->D : 0.0));
+    const dim3 grid(wgs, tiles_m);
+    const SkinnyGruBwd g0{};
+    if (G != nullptr) {
+        if (rw == 1) skinny_deep_dispatch<1, 1>(cp, kc, grid, stream, L, *G);
+        else if (rw == 2) skinny_deep_dispatch<2, 1>(cp, kc, grid, stream, L, *G);
+        else skinny_deep_dispatch<4, 1>(cp, kc, grid, stream, L, *G);
+    } else {
+        if (rw == 1) skinny_deep_dispatch<1, 0>(cp, kc, grid, stream, L, g0);
+        else if (rw == 2) skinny_deep_dispatch<2, 0>(cp, kc, grid, stream, L, g0);
+        else skinny_deep_dispatch<4, 0>(cp, kc, grid, stream, L, g0);
+    }
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
 }  // namespace drm

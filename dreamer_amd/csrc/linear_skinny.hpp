@@ -195,4 +195,103 @@ __global__ __launch_bounds__(256) void k_skinny(const SkinnyLaunch L) {
     if (writer) P.Y[(int64_t)m * P.ldy + n] = tot + bias;
 }
 
+// ---- deeper K (up to 512 * KC) without LayerNorm: the reverse-time observe scan -----------------------
+// Epilogue 0: Y = acc + bias.  Epilogue 1 (one problem, columns = GRU units j): the GRU cell's
+// elementwise backward (what autograd computes for torch.nn.GRUCell):
+//     dh = acc + g_h + next_scale * (dhu_next + dhw_next)        (the last two: the path through h_{t+1})
+//     d(gi_n) = dh (1-u)(1-n^2),  d(gh_n) = d(gi_n) r,  d(gi_r) = d(gh_r) = d(gi_n) gh_n r (1-r),
+//     d(gi_u) = d(gh_u) = dh (h_in - n) u (1-u),  dhu = dh u
+struct SkinnyGruBwd {
+    const float* g_h; int64_t ldgh;          // (M, D) upstream gradient wrt h_t
+    const float* dhu_next;                   // (M, D) dh*u of step t+1 (row stride D) or nullptr at the last step
+    const float* dhw_next;                   // (M, D) d(gh)[t+1] W_hh (row stride D)
+    const float* next_scale; int64_t ldns;   // (M) continue flag of step t+1
+    const float* gates; int64_t ldg;         // (M, 4D): r, u, n, gh_n
+    const float* h_in; int64_t ldhi;         // (M, D)
+    float* dgi; float* dgh; int64_t lddg;    // (M, 3D)
+    float* dhu;                              // (M, D), row stride D (may alias dhu_next)
+    int D;
+};
+
+template <int RW, int CP, int KC, int EPI>
+__global__ __launch_bounds__(256) void k_skinny_deep(const SkinnyLaunch L, const SkinnyGruBwd G) {
+    constexpr int NV = RW * CP;
+    static_assert(NV >= 2 && NV <= 64 && (NV & (NV - 1)) == 0, "RW*CP must be a power of two in [2, 64]");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int pi = L.np - 1;
+    while (pi > 0 && (int)blockIdx.x < L.p[pi].wg_begin) --pi;
+    const SkinnyProblem& P = L.p[pi];
+    const int cg = blockIdx.x - P.wg_begin;
+    const int K = P.K;
+    const int row0 = blockIdx.y * (4 * RW) + wave * RW;
+
+    float x[RW][8 * KC], w[CP][8 * KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const int kA = kc * 512 + 4 * lane, kB = kA + 256;
+        const bool vA = kA < K, vB = kB < K;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float* xp = P.X + (int64_t)min(row0 + r, L.M - 1) * P.ldx;
+            const float4 a = ld4(xp + kA, vA), b = ld4(xp + kB, vB);
+            x[r][8 * kc + 0] = a.x; x[r][8 * kc + 1] = a.y; x[r][8 * kc + 2] = a.z; x[r][8 * kc + 3] = a.w;
+            x[r][8 * kc + 4] = b.x; x[r][8 * kc + 5] = b.y; x[r][8 * kc + 6] = b.z; x[r][8 * kc + 7] = b.w;
+        }
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            const int n = cg * CP + c;
+            const bool ok = n < P.N;
+            const float* wp = P.W + (int64_t)(ok ? n : 0) * P.ldw;
+            const float4 a = ld4(wp + kA, ok && vA), b = ld4(wp + kB, ok && vB);
+            w[c][8 * kc + 0] = a.x; w[c][8 * kc + 1] = a.y; w[c][8 * kc + 2] = a.z; w[c][8 * kc + 3] = a.w;
+            w[c][8 * kc + 4] = b.x; w[c][8 * kc + 5] = b.y; w[c][8 * kc + 6] = b.z; w[c][8 * kc + 7] = b.w;
+        }
+    }
+    const int idx = halving_index<NV>(lane);
+    const int m = row0 + idx / CP;
+    const int n = cg * CP + idx % CP;
+    const bool writer = lane < NV && m < L.M && n < P.N;
+    // epilogue operands, requested with everything else
+    float bias = 0.f, rr = 0.f, uu = 0.f, nn = 0.f, ghn = 0.f, hin = 0.f;
+    if (EPI == 0) {
+        bias = (writer && P.bias != nullptr) ? P.bias[n] : 0.f;
+        if (writer && P.add != nullptr) bias += P.add[(int64_t)m * P.ldadd + n];
+    } else if (writer) {
+        const int D = G.D;
+        bias = G.g_h[(int64_t)m * G.ldgh + n];
+        if (G.dhu_next != nullptr)
+            bias += G.next_scale[(int64_t)m * G.ldns] * (G.dhu_next[(int64_t)m * D + n] + G.dhw_next[(int64_t)m * D + n]);
+        const float* gt = G.gates + (int64_t)m * G.ldg;
+        rr = gt[n]; uu = gt[D + n]; nn = gt[2 * D + n]; ghn = gt[3 * D + n];
+        hin = G.h_in[(int64_t)m * G.ldhi + n];
+    }
+
+    float acc[NV];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8 * KC; ++i) a = fmaf(x[r][i], w[c][i], a);
+            acc[r * CP + c] = a;
+        }
+    const float tot = halving_sum64<NV>(acc, lane);
+    if (!writer) return;
+    if (EPI == 0) {
+        P.Y[(int64_t)m * P.ldy + n] = tot + bias;
+    } else {
+        const int D = G.D;
+        const float dh = tot + bias;
+        const float dn_pre = dh * (1.0f - uu) * (1.0f - nn * nn);
+        const float du_pre = dh * (hin - nn) * uu * (1.0f - uu);
+        const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
+        float* gi = G.dgi + (int64_t)m * G.lddg;
+        float* gh = G.dgh + (int64_t)m * G.lddg;
+        gi[n] = dr_pre; gi[D + n] = du_pre; gi[2 * D + n] = dn_pre;
+        gh[n] = dr_pre; gh[D + n] = du_pre; gh[2 * D + n] = dn_pre * rr;
+        G.dhu[(int64_t)m * D + n] = dh * uu;
+    }
+}
+
 }  // namespace drm

@@ -259,6 +259,46 @@ __global__ __launch_bounds__(256) void k_observe_x_bulk(const XBulkArgs P) {
     }
 }
 
+// Straight-through sample / unimix / log-softmax backward of one step, one workgroup per sequence:
+//     dz = scale * dz_raw + g_z;  s1 = sum_k y dz;  dl = y (dz - s1) wmix;  s2 = sum_k dl;
+//     d(post) = dl - psoft s2 + g_post          (sums over the 32 classes of a latent: 8 lanes x 4)
+struct StBwdArgs {
+    const float* dz_raw; int64_t lddz;       // (B, L*32) or nullptr (last step: no path through z)
+    const float* scale; int64_t lds;         // (B) continue flag of step t+1
+    const float* g_z; const float* y; const float* wmix; const float* psoft; const float* g_post; int64_t ldl;
+    float* dpost; int64_t lddp;
+    int L;
+};
+__global__ __launch_bounds__(256) void k_observe_st_bwd(const StBwdArgs P) {
+    const int b = blockIdx.x, tid = threadIdx.x, sub = tid & 7;
+    const float sc = P.dz_raw ? P.scale[(int64_t)b * P.lds] : 0.f;
+    for (int l = tid >> 3; l < P.L; l += 32) {
+        const int64_t o = (int64_t)b * P.ldl + l * 32 + sub * 4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 dr = P.dz_raw ? *reinterpret_cast<const float4*>(P.dz_raw + (int64_t)b * P.lddz + l * 32 + sub * 4) : z4;
+        const float4 gz = *reinterpret_cast<const float4*>(P.g_z + o);
+        const float4 yy = *reinterpret_cast<const float4*>(P.y + o);
+        const float4 wm = *reinterpret_cast<const float4*>(P.wmix + o);
+        const float4 ps = *reinterpret_cast<const float4*>(P.psoft + o);
+        const float4 gp = *reinterpret_cast<const float4*>(P.g_post + o);
+        const float dz[4] = {dr.x * sc + gz.x, dr.y * sc + gz.y, dr.z * sc + gz.z, dr.w * sc + gz.w};
+        const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, wv[4] = {wm.x, wm.y, wm.z, wm.w};
+        const float pv[4] = {ps.x, ps.y, ps.z, ps.w}, gv[4] = {gp.x, gp.y, gp.z, gp.w};
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s1 += yv[i] * dz[i];
+        s1 = group_sum<8>(s1);
+        float dl[4], s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dl[i] = yv[i] * (dz[i] - s1) * wv[i]; s2 += dl[i]; }
+        s2 = group_sum<8>(s2);
+        float4 out;
+        out.x = dl[0] - pv[0] * s2 + gv[0]; out.y = dl[1] - pv[1] * s2 + gv[1];
+        out.z = dl[2] - pv[2] * s2 + gv[2]; out.w = dl[3] - pv[3] * s2 + gv[3];
+        *reinterpret_cast<float4*>(P.dpost + (int64_t)b * P.lddp + l * 32 + sub * 4) = out;
+    }
+}
+
 // defined in imagine.hip's translation unit as well; both are file-local
 __global__ __launch_bounds__(256) void k_transpose_cols_o(const float* __restrict__ W, int64_t ldw, int col0, int ncols,
                                                            int nrows, float* __restrict__ out) {
@@ -517,7 +557,9 @@ extern "C" int drm_observe_forward_f32(const drm_observe_weights* w, const drm_o
 
 extern "C" size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t B) {
     if (!dims || check_observe_dims(*dims) != DRM_OK || B < 1) return 0;
-    return (size_t)B * 3 * dims->D * sizeof(float);   // dh*u, and two alternating dh_next buffers
+    // many sequences: dh*u and two alternating dh_next buffers; few: dh*u, d(gh) W_hh, and dz_raw
+    const size_t a = (size_t)B * 3 * dims->D, b = (size_t)B * (2 * (size_t)dims->D + (size_t)dims->L * dims->K);
+    return (a > b ? a : b) * sizeof(float);
 }
 
 extern "C" int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io, drm_stream_t stream) {
@@ -533,6 +575,52 @@ extern "C" int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_
                 DRM_EINVAL, "workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
     float* dhu = (float*)io->workspace;
+    if (B <= SKINNY_MAX_ROWS && 3 * D <= 1536 && LK <= 1536) {
+        // ---- few sequences: three launches per step on ~256 workgroups each.  z enters the GRU only
+        // through gi = W_ih x and x is linear in the one-hot z, so d(z_t) = d(gi_{t+1}) gz^T with the
+        // forward pass's packed table gz (it follows lin_zT in the pack buffer); d(x) itself is needed
+        // only for the weight gradients and is formed for all steps at once after the loop.
+        DRM_REQUIRE(io->workspace_bytes >= (size_t)B * (2 * (size_t)D + LK) * sizeof(float), DRM_EINVAL, "workspace too small");
+        const ObsPack pl = obs_pack_layout(d);
+        const float* gz = io->lin_zT + pl.gz;
+        float* dhw = dhu + (size_t)B * D;
+        float* dzraw = dhw + (size_t)B * D;
+        const int64_t TD_ = (int64_t)T * D, T3D_ = (int64_t)T * 3 * D, TLK_ = (int64_t)T * LK;
+        for (int t = T - 1; t >= 0; --t) {
+            const bool last = t == T - 1;
+            if (!last) {
+                ProblemSpec p[2] = {
+                    {io->d_gi + (size_t)(t + 1) * 3 * D, T3D_, nullptr, nullptr, gz, 3 * D, nullptr, nullptr, 0, dzraw, LK, LK, 3 * D},
+                    {io->d_gh + (size_t)(t + 1) * 3 * D, T3D_, nullptr, nullptr, io->gru_w_hhT, 3 * D, nullptr, nullptr, 0, dhw, D, D,
+                     3 * D}};
+                if (int rc = launch_skinny_deep(p, 2, B, s)) return rc;
+            }
+            {
+                StBwdArgs a{};
+                a.dz_raw = last ? nullptr : dzraw; a.lddz = LK; a.scale = last ? nullptr : io->c_prev + (t + 1); a.lds = T;
+                a.g_z = io->g_z + (size_t)t * LK; a.y = io->y + (size_t)t * LK; a.wmix = io->wmix + (size_t)t * LK;
+                a.psoft = io->psoft + (size_t)t * LK; a.g_post = io->g_post + (size_t)t * LK; a.ldl = TLK_;
+                a.dpost = io->d_post + (size_t)t * LK; a.lddp = TLK_; a.L = L;
+                ProfScope prof(PC_SAMPLE, s, 12.0 * B * LK, 28.0 * B * LK);
+                k_observe_st_bwd<<<dim3(B), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+            {
+                ProblemSpec p{io->d_post + (size_t)t * LK, TLK_, nullptr, nullptr, io->fc_w_hT, LK, nullptr, nullptr, 0, dhu, D, D, LK};
+                SkinnyGruBwd G{};
+                G.g_h = io->g_h + (size_t)t * D; G.ldgh = TD_;
+                G.dhu_next = last ? nullptr : dhu; G.dhw_next = dhw; G.next_scale = last ? nullptr : io->c_prev + (t + 1); G.ldns = T;
+                G.gates = io->gates + (size_t)t * 4 * D; G.ldg = (int64_t)T * 4 * D;
+                G.h_in = io->h_in + (size_t)t * D; G.ldhi = TD_;
+                G.dgi = io->d_gi + (size_t)t * 3 * D; G.dgh = io->d_gh + (size_t)t * 3 * D; G.lddg = T3D_;
+                G.dhu = dhu; G.D = D;
+                if (int rc = launch_skinny_deep(&p, 1, B, s, &G)) return rc;
+            }
+        }
+        // d(x) = d(gi) W_ih for all (b, t) rows at once
+        ProblemSpec px{io->d_gi, 3 * D, nullptr, nullptr, io->gru_w_ihT, 3 * D, nullptr, nullptr, 0, io->d_x, D, D, 3 * D};
+        return launch_big(&px, 1, B * T, nullptr, 0, 0, 0, s);
+    }
     float* dhn[2] = {dhu + (size_t)B * D, dhu + (size_t)2 * B * D};
     const int64_t TD = (int64_t)T * D, T3D = (int64_t)T * 3 * D, T4D = (int64_t)T * 4 * D, TLK = (int64_t)T * LK;
     DRM_HIP(hipMemsetAsync(dhn[0], 0, (size_t)B * D * sizeof(float), s));

@@ -279,7 +279,8 @@ typedef struct drm_observe_bwd_io {
     const float* fc_w_hT;     /* (D, L*K)  = enc.fc.0.weight[:, conv_out:]^T */
     const float* gru_w_ihT;   /* (D, 3D)   = weight_ih^T */
     const float* gru_w_hhT;   /* (D, 3D)   = weight_hh^T */
-    const float* lin_zT;      /* (L*K, D)  = seq.linear.weight[:, :L*K]^T (the forward pack's table) */
+    const float* lin_zT;      /* (L*K, D)  = seq.linear.weight[:, :L*K]^T: the START of the buffer written by
+                                 drm_pack_observe (the other packed tables are read at their offsets behind it) */
     float* d_gi;              /* (B,T,3D) */
     float* d_gh;              /* (B,T,3D) */
     float* d_x;               /* (B,T,D) */
