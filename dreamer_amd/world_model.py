@@ -76,10 +76,55 @@ class SequenceModel(nn.Module):
         return self.gru(x, h_prev)
 
 
+class _ConvBiasFn(torch.autograd.Function):
+    """A (transposed) convolution whose bias gradient is reduced over the contiguous H*W axis first.
+
+    Autograd's own bias gradient is one strided reduction over (N, H, W): 284 us for a (1024, 32, 32, 32)
+    gradient on MI355X against 33 us for the two-step form, twice per world-model update.  Input and
+    weight gradients come from the same backend routine autograd would call."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, transposed, stride, padding):
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (transposed, stride, padding)
+        if transposed:
+            return F.conv_transpose2d(x, weight, bias, stride=stride, padding=padding)
+        return F.conv2d(x, weight, bias, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        transposed, stride, padding = ctx.conf
+        g = g.contiguous()
+        gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1], transposed,
+                                                        [0, 0], 1, [ctx.needs_input_grad[0], True, False])
+        gb = g.view(g.shape[0], g.shape[1], -1).sum(2).sum(0)
+        return gx, gw, gb, None, None, None
+
+
+def _conv_forward(mod, x, transposed: bool):
+    hw = x.shape[-1] * x.shape[-2] * (4 if transposed else 1) // (1 if transposed else 4)   # output H*W at stride 2
+    if x.is_cuda and torch.is_grad_enabled() and mod.bias is not None and mod.bias.requires_grad and hw >= 256:
+        return _ConvBiasFn.apply(x, mod.weight, mod.bias, transposed, mod.stride, mod.padding)
+    return None
+
+
+class _Conv2d(nn.Conv2d):
+    def forward(self, x):
+        y = _conv_forward(self, x, False)
+        return y if y is not None else super().forward(x)
+
+
+class _ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x):
+        y = _conv_forward(self, x, True)
+        return y if y is not None else super().forward(x)
+
+
 def _conv_tower(channels, spatial, transpose: bool):
     """Conv(k4,s2,p1) + LayerNorm[C,H,W] + SiLU per stage; spatial[i] is the OUTPUT size of stage i."""
     mods = []
-    conv = nn.ConvTranspose2d if transpose else nn.Conv2d
+    conv = _ConvTranspose2d if transpose else _Conv2d
     for i in range(len(channels) - 1):
         mods += [conv(channels[i], channels[i + 1], 4, stride=2, padding=1),
                  nn.LayerNorm([channels[i + 1], spatial[i][0], spatial[i][1]]), nn.SiLU()]
@@ -156,7 +201,7 @@ class Decoder(nn.Module):
                                 nn.SiLU())
         sizes = [(self.base_h << s, self.base_w << s) for s in (1, 2, 3)]
         self.deconv = nn.Sequential(*_conv_tower([8 * c, 4 * c, 2 * c, c], sizes, True),
-                                    nn.ConvTranspose2d(c, C, 4, stride=2, padding=1), nn.Sigmoid())
+                                    _ConvTranspose2d(c, C, 4, stride=2, padding=1), nn.Sigmoid())
 
     def forward(self, h_t, z_t):
         B = h_t.size(0)
