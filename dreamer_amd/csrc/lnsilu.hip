@@ -1,0 +1,212 @@
+// LayerNorm over a whole sample (normalized_shape = [C, H, W], elementwise affine) fused with SiLU,
+// forward and backward: the stage nonlinearity of the encoder / decoder conv towers
+// (lib/world_model.py:94-108, :290-302).  HBM-bound; E = C*H*W elements per sample, N samples.
+//
+//   forward : y = SiLU((x - mean) * rstd * gamma + beta); mean, rstd saved per sample
+//   backward: u = xhat*gamma + beta, s = sigmoid(u), du = dy * s * (1 + u (1 - s)), g = du * gamma
+//             dx = rstd * (g - mean_E(g) - xhat * mean_E(g xhat))
+//             dgamma[e] = sum_n du xhat,  dbeta[e] = sum_n du
+//
+// One 1024-thread workgroup per sample keeps the sample in registers (<= 8 float4 per thread) between
+// the statistics and the output pass, so x (and dy) are read once.  The parameter gradients are a
+// reduction over samples: a second kernel walks the samples with one thread per four elements and
+// writes one partial row per sample slice (no atomics; the caller adds the slices).
+#include "common.hpp"
+
+namespace drm {
+
+constexpr int LNS_THREADS = 1024;
+
+__device__ __forceinline__ float block_sum_1024(float v, float* s16) {
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s16[i];
+    return t;
+}
+
+template <int NV>
+__global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_fwd(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ Y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int E, float eps) {
+    __shared__ float s16[16];
+    const int64_t n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* x = X + n * E;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * LNS_THREADS + tid) * 4;
+        v[i] = e < E ? *reinterpret_cast<const float4*>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = block_sum_1024(s, s16) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * LNS_THREADS + tid) * 4;
+        if (e < E) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum_1024(q, s16) / (float)E + eps);
+    if (tid == 0) { mean_out[n] = mean; rstd_out[n] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * LNS_THREADS + tid) * 4;
+        if (e < E) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + e);
+            const float4 b = *reinterpret_cast<const float4*>(beta + e);
+            float4 o;
+            o.x = silu_f((v[i].x - mean) * rstd * g.x + b.x);
+            o.y = silu_f((v[i].y - mean) * rstd * g.y + b.y);
+            o.z = silu_f((v[i].z - mean) * rstd * g.z + b.z);
+            o.w = silu_f((v[i].w - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<float4*>(Y + n * E + e) = o;
+        }
+    }
+}
+
+__device__ __forceinline__ float dsilu_times(float dy, float u) {
+    const float s = 1.0f / (1.0f + expf(-u));
+    return dy * s * (1.0f + u * (1.0f - s));
+}
+
+template <int NV>
+__global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __restrict__ X, const float* __restrict__ dY,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                               float* __restrict__ dX, int E) {
+    __shared__ float s16[16];
+    const int64_t n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float mean = mean_in[n], rstd = rstd_in[n];
+    float4 xh[NV], g[NV];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * LNS_THREADS + tid) * 4;
+        if (e < E) {
+            const float4 xv = *reinterpret_cast<const float4*>(X + n * E + e);
+            const float4 dy = *reinterpret_cast<const float4*>(dY + n * E + e);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
+            const float4 be = *reinterpret_cast<const float4*>(beta + e);
+            xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+            g[i].x = dsilu_times(dy.x, xh[i].x * ga.x + be.x) * ga.x;
+            g[i].y = dsilu_times(dy.y, xh[i].y * ga.y + be.y) * ga.y;
+            g[i].z = dsilu_times(dy.z, xh[i].z * ga.z + be.z) * ga.z;
+            g[i].w = dsilu_times(dy.w, xh[i].w * ga.w + be.w) * ga.w;
+            sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            sgx += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        } else {
+            xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = xh[i];
+        }
+    }
+    const float mg = block_sum_1024(sg, s16) / (float)E;
+    const float mgx = block_sum_1024(sgx, s16) / (float)E;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * LNS_THREADS + tid) * 4;
+        if (e < E) {
+            float4 o;
+            o.x = rstd * (g[i].x - mg - xh[i].x * mgx);
+            o.y = rstd * (g[i].y - mg - xh[i].y * mgx);
+            o.z = rstd * (g[i].z - mg - xh[i].z * mgx);
+            o.w = rstd * (g[i].w - mg - xh[i].w * mgx);
+            *reinterpret_cast<float4*>(dX + n * E + e) = o;
+        }
+    }
+}
+
+// grid (ceil(E / 1024), slices): thread = four elements, walks the samples of its slice
+__global__ __launch_bounds__(256) void k_lnsilu_bwd_params(const float* __restrict__ X, const float* __restrict__ dY,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           float* __restrict__ part, int N, int E, int per_slice) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= E) return;
+    const int n0 = blockIdx.y * per_slice, n1 = min(n0 + per_slice, N);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
+    const float4 be = *reinterpret_cast<const float4*>(beta + e);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    for (int n = n0; n < n1; ++n) {
+        const float mean = mean_in[n], rstd = rstd_in[n];
+        const float4 xv = *reinterpret_cast<const float4*>(X + (int64_t)n * E + e);
+        const float4 dy = *reinterpret_cast<const float4*>(dY + (int64_t)n * E + e);
+        const float x0 = (xv.x - mean) * rstd, x1 = (xv.y - mean) * rstd, x2 = (xv.z - mean) * rstd, x3 = (xv.w - mean) * rstd;
+        const float d0 = dsilu_times(dy.x, x0 * ga.x + be.x), d1 = dsilu_times(dy.y, x1 * ga.y + be.y);
+        const float d2 = dsilu_times(dy.z, x2 * ga.z + be.z), d3 = dsilu_times(dy.w, x3 * ga.w + be.w);
+        dg.x += d0 * x0; dg.y += d1 * x1; dg.z += d2 * x2; dg.w += d3 * x3;
+        db.x += d0; db.y += d1; db.z += d2; db.w += d3;
+    }
+    float* row = part + (int64_t)blockIdx.y * 2 * E;
+    *reinterpret_cast<float4*>(row + e) = dg;
+    *reinterpret_cast<float4*>(row + E + e) = db;
+}
+
+static int lns_check(int64_t N, int E, const void* a, const void* b, const void* c) {
+    DRM_REQUIRE(N >= 1 && N < (1 << 30) && E >= 4 && E % 4 == 0 && E <= 32768, DRM_ENOTSUP,
+                "N=%lld, E=%d: E must be a multiple of 4, at most 32768", (long long)N, E);
+    DRM_REQUIRE(a && b && c && aligned16(a) && aligned16(b) && aligned16(c), DRM_EINVAL, "null or misaligned pointer");
+    return DRM_OK;
+}
+
+}  // namespace drm
+
+using namespace drm;
+
+extern "C" int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                   int64_t N, int32_t E, float eps, drm_stream_t stream) {
+    if (int rc = lns_check(N, E, x, gamma, beta)) return rc;
+    DRM_REQUIRE(y && mean && rstd && aligned16(y), DRM_EINVAL, "null or misaligned output");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PC_ELEMENTWISE, s, 14.0 * N * E, 8.0 * N * E + 8.0 * E);
+    const dim3 grid((unsigned)N), block(LNS_THREADS);
+    if (E <= 4096) k_lnsilu_fwd<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
+    else if (E <= 8192) k_lnsilu_fwd<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
+    else if (E <= 16384) k_lnsilu_fwd<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
+    else k_lnsilu_fwd<8><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+extern "C" int32_t drm_ln_silu_slices(int64_t N, int32_t E) {
+    // enough (element block, sample slice) workgroups to fill the chip, at least 8 samples per slice
+    const int64_t eb = (E / 4 + 255) / 256;
+    int64_t slices = (1024 + eb - 1) / eb;
+    if (slices > N / 8) slices = N / 8;
+    if (slices < 1) slices = 1;
+    return (int32_t)slices;
+}
+
+extern "C" int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                    const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E,
+                                    drm_stream_t stream) {
+    if (int rc = lns_check(N, E, x, gamma, beta)) return rc;
+    DRM_REQUIRE(dy && mean && rstd && dx && param_partials && aligned16(dy) && aligned16(dx) && aligned16(param_partials),
+                DRM_EINVAL, "null or misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)N), block(LNS_THREADS);
+    {
+        ProfScope prof(PC_ELEMENTWISE, s, 30.0 * N * E, 12.0 * N * E + 8.0 * E);
+        if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
+        else if (E <= 8192) k_lnsilu_bwd_dx<2><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
+        else if (E <= 16384) k_lnsilu_bwd_dx<4><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
+        else k_lnsilu_bwd_dx<8><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
+        DRM_LAUNCH_CHECK();
+    }
+    const int slices = drm_ln_silu_slices(N, E);
+    const int per_slice = (int)((N + slices - 1) / slices);
+    ProfScope prof(PC_ELEMENTWISE, s, 24.0 * N * E, 8.0 * N * E + 8.0 * slices * E);
+    k_lnsilu_bwd_params<<<dim3((E / 4 + 255) / 256, slices), dim3(256), 0, s>>>(x, dy, gamma, beta, mean, rstd, param_partials,
+                                                                                 (int)N, E, per_slice);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}

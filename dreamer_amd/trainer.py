@@ -74,11 +74,14 @@ class _GraphedUpdate:
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        rng = torch.cuda.get_rng_state()
         with torch.cuda.stream(side):   # settle allocator / autograd state on a side stream: loss + backward only
             for _ in range(2):
                 self.grads.zero()
                 self.loss_fn(*self.static).backward()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        torch.cuda.set_rng_state(rng)   # the rehearsal drew noise; the recorded update must continue the eager sequence
         self.g_loss = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_loss):
             self.grads.zero()
@@ -158,7 +161,8 @@ class Learner:
         # ---- imagination from the last posterior states, with the updated world model ----
         start: WorldModelState = wm_info["state"]
         im = imagine(self.world_model, self.actor, self.critic,
-                     WorldModelState(h=start.h.detach(), z=start.z.detach()), cfg.imagination_horizon, cfg.gamma, cfg.lam)
+                     WorldModelState(h=start.h.detach(), z=start.z.detach()), cfg.imagination_horizon, cfg.gamma, cfg.lam,
+                     **({"persistent": True} if self.graph_updates else {}))
         Hs = WorldModelState(h=im["h"], z=im["z"])
         returns, values, actions = im["lam_returns"], im["values"], im["actions"]
         if self.graph_updates and self.eager_updates >= 3:

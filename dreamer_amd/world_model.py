@@ -121,6 +121,45 @@ class _ConvTranspose2d(nn.ConvTranspose2d):
         return y if y is not None else super().forward(x)
 
 
+class _LayerNormSiLUFn(torch.autograd.Function):
+    """nn.LayerNorm([C, H, W]) followed by nn.SiLU as one HIP kernel forward and two backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        from . import _native as N
+        x = x.contiguous()
+        y, mean, rstd = N.ln_silu_forward(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _native as N
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        dx, dparams = N.ln_silu_backward(x, dy.contiguous(), weight, bias, mean, rstd)
+        return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None
+
+
+class _Tower(nn.Sequential):
+    """nn.Sequential whose (LayerNorm over the whole sample, SiLU) pairs run fused on the GPU; the
+    modules, and therefore the state-dict keys, are those of the plain Sequential."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.SiLU) and x.is_cuda
+                    and x.dtype == torch.float32 and x.dim() == 4 and tuple(m.normalized_shape) == tuple(x.shape[1:])
+                    and m.weight.numel() % 4 == 0 and m.weight.numel() <= 32768):
+                x = _LayerNormSiLUFn.apply(x, m.weight, m.bias, m.eps)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 def _conv_tower(channels, spatial, transpose: bool):
     """Conv(k4,s2,p1) + LayerNorm[C,H,W] + SiLU per stage; spatial[i] is the OUTPUT size of stage i."""
     mods = []
@@ -142,7 +181,7 @@ class Encoder(nn.Module):
         self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
         c = base_cnn_channels
         sizes = [(H >> s, W >> s) for s in (1, 2, 3, 4)]
-        self.conv = nn.Sequential(*_conv_tower([C, c, 2 * c, 4 * c, 8 * c], sizes, False), nn.Flatten())
+        self.conv = _Tower(*_conv_tower([C, c, 2 * c, 4 * c, 8 * c], sizes, False), nn.Flatten())
         self.conv_out_size = 8 * c * (H // 16) * (W // 16)
         self.fc = nn.Sequential(nn.Linear(self.conv_out_size + hidden_size, num_latents * classes_per_latent))
 
@@ -200,7 +239,7 @@ class Decoder(nn.Module):
         self.fc = nn.Sequential(nn.Linear(hidden_size + num_latents * classes_per_latent, 8 * c * self.base_h * self.base_w),
                                 nn.SiLU())
         sizes = [(self.base_h << s, self.base_w << s) for s in (1, 2, 3)]
-        self.deconv = nn.Sequential(*_conv_tower([8 * c, 4 * c, 2 * c, c], sizes, True),
+        self.deconv = _Tower(*_conv_tower([8 * c, 4 * c, 2 * c, c], sizes, True),
                                     _ConvTranspose2d(c, C, 4, stride=2, padding=1), nn.Sigmoid())
 
     def forward(self, h_t, z_t):

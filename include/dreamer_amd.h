@@ -291,6 +291,19 @@ typedef struct drm_observe_bwd_io {
 size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t B);
 int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io, drm_stream_t stream);
 
+/* ---- LayerNorm over a whole sample fused with SiLU: the stage nonlinearity of the conv towers,
+ * nn.LayerNorm([C,H,W]) followed by nn.SiLU (lib/world_model.py:94-108, :290-302) --------------
+ * x, y, dy, dx: (N, E) contiguous with E = C*H*W (a multiple of 4, at most 32768); gamma, beta: (E).
+ *   forward : y = SiLU((x - mean_n) * rstd_n * gamma + beta), biased variance, rstd = 1/sqrt(var + eps);
+ *             mean, rstd (N) are saved for the backward pass.
+ *   backward: dx (N, E), and param_partials (slices, 2, E) whose sum over the first axis is
+ *             [d gamma; d beta] (slices = drm_ln_silu_slices(N, E); no atomics are used). */
+int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int64_t N, int32_t E, float eps, drm_stream_t stream);
+int32_t drm_ln_silu_slices(int64_t N, int32_t E);
+int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E, drm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
