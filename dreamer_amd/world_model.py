@@ -18,6 +18,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Any, Dict, Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -144,9 +146,13 @@ class _Tower(nn.Sequential):
     """nn.Sequential whose (LayerNorm over the whole sample, SiLU) pairs run fused on the GPU; the
     modules, and therefore the state-dict keys, are those of the plain Sequential."""
 
+    fuse = os.environ.get("DRM_NO_LN_FUSION", "0") != "1"
+
     def forward(self, x):
         mods = list(self)
         i = 0
+        if not self.fuse or not x.is_cuda:
+            return super().forward(x)
         while i < len(mods):
             m = mods[i]
             if (isinstance(m, nn.LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.SiLU) and x.is_cuda
