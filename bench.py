@@ -7,7 +7,7 @@ One "step" is one imagination block (lib/trainer.py:176-224 of the reference: ac
 draw -> prior RSSM step, H = 15 times; reward / continue heads; critic value; lambda-return) for
 B start states, including the generation of its Exp(1) noise.  Weights are fixed (random init of
 the default architecture, heads made non-zero), start states synthetic.  Default workload:
-BASELINE config 2, the default config (B = 16 trajectories per GPU).  With N > 1 every rank runs
+the reference's default configuration (B = 16 trajectories per GPU).  With N > 1 every rank runs
 its own B trajectories (trajectories are independent: no collective on the data path) and the
 reported value is the whole-job rate (weak scaling).
 
@@ -168,9 +168,38 @@ def measure_train(device, world, rank, steps, warmup, fence):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ups = steps / dt
-    return {"updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
+    acting = measure_acting(learner, device, rng)
+    return {"acting": acting, "updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
             "replayed_steps_per_sec": ups * world * cfg.batch_size * cfg.batch_length, "steps": steps, "warmup": warmup,
             "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}
+
+
+def measure_acting(learner, device, rng, steps=200):
+    """Policy latency per environment step (lib/trainer.py:126-151): one 12 KB frame host -> device, the
+    B = 1 posterior step, the actor, and the action back on the host.  `full_step` evaluates the whole
+    `WorldModel.step` (prior, reward, continue and decoder heads too) as the reference's loop does."""
+    wm, actor = learner.world_model, learner.actor
+    frames = rng.integers(0, 256, size=(8, 3, 64, 64), dtype="uint8")
+    out = {}
+    for name in ("act_step", "full_step"):
+        state = wm.init_state(1, device)
+        last_action = torch.zeros(1, dtype=torch.long, device=device)
+        last_cont = torch.ones(1, dtype=torch.float32, device=device)
+        for i in range(steps + 20):
+            if i == 20:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            with torch.no_grad():
+                obs_t = torch.as_tensor(frames[i % 8], dtype=torch.float32, device=device).unsqueeze(0) / 255.0
+                if name == "act_step":
+                    state = wm.act_step(state, last_action, obs_t, last_cont)
+                else:
+                    state, _ = wm.step(state, last_action, obs_t, last_cont)
+                action = actor(state).sample().item()
+            last_action.fill_(action)
+        torch.cuda.synchronize()
+        out["ms_per_env_step_" + name] = (time.perf_counter() - t0) / steps * 1e3
+    return out
 
 
 def progress(msg):
@@ -294,8 +323,12 @@ def main():
     train = None
     if args.train_steps > 0:
         progress("training updates: building the learner, warm-up (includes the convolution kernel search)")
-        train = measure_train(device, world, rank, args.train_steps, 6, fence)
-        progress(f"training updates: {train['ms_per_update']:.2f} ms per update")
+        try:
+            train = measure_train(device, world, rank, args.train_steps, 6, fence)
+            progress(f"training updates: {train['ms_per_update']:.2f} ms per update")
+        except Exception as e:  # the headline line above is already measured: report the failure beside it
+            train = {"error": f"{type(e).__name__}: {e}"}
+            progress(f"training updates failed: {train['error']}")
 
     if rank == 0:
         value = world * B * H * args.steps / elapsed

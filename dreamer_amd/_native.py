@@ -106,6 +106,7 @@ SIGNATURES = {
     "drm_sample_categorical_st": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_onehot_to_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "drm_copy_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_fused_linear_f32": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_pack_imagine_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
@@ -244,6 +245,17 @@ def onehot_to_index(z: torch.Tensor) -> torch.Tensor:
     check(lib().drm_onehot_to_index(z.data_ptr(), z.numel() // K, K, idx.data_ptr(), stream_ptr(z.device)),
           "drm_onehot_to_index")
     return idx
+
+
+def copy_pair(a_dst: torch.Tensor, a_src: torch.Tensor, b_dst: torch.Tensor, b_src: torch.Tensor) -> None:
+    """a_dst <- a_src and b_dst <- b_src (dense tensors of equal byte size each) in one launch."""
+    require_cuda(a_dst)
+    for dst, src in ((a_dst, a_src), (b_dst, b_src)):
+        if not (dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()):
+            raise ValueError("copy_pair needs dense tensors of the same dtype and size")
+    check(lib().drm_copy_pair(a_src.data_ptr(), a_dst.data_ptr(), a_dst.numel() * a_dst.element_size(),
+                              b_src.data_ptr(), b_dst.data_ptr(), b_dst.numel() * b_dst.element_size(),
+                              stream_ptr(a_dst.device)), "drm_copy_pair")
 
 
 def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None, bf16: bool = False):

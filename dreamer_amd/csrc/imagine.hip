@@ -406,10 +406,7 @@ struct ScalarHead {
 };
 struct ScalarHeadsArgs { ScalarHead h[2]; int nh; int rows; int M; };
 
-__global__ __launch_bounds__(256) void k_scalar_heads(const ScalarHeadsArgs P) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= P.rows) return;
+__device__ __forceinline__ void scalar_heads_row(const ScalarHeadsArgs& P, int row, int lane) {
     for (int hi = 0; hi < P.nh; ++hi) {
         const ScalarHead& Hd = P.h[hi];
         const float* pre = Hd.pre + (int64_t)row * Hd.ldp;
@@ -447,13 +444,13 @@ __global__ __launch_bounds__(256) void k_scalar_heads(const ScalarHeadsArgs P) {
 
 // critic value: symexp(sum softmax(logits) * buckets), one wave per row (lib/critic.py:94-101);
 // also copies the value of each trajectory's last step to v_last (lib/trainer.py:212-215).
-__global__ __launch_bounds__(256) void k_critic_value(const float* __restrict__ logits, int64_t ldl, int NB,
-                                                       const float* __restrict__ buckets, int rows, int H,
-                                                       float* __restrict__ V, float* __restrict__ v_last) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    const float* lg = logits + (int64_t)row * ldl;
+struct CriticValueArgs { const float* logits; int64_t ldl; int NB; const float* buckets; int H; float* V; float* v_last; };
+
+__device__ __forceinline__ void critic_value_row(const CriticValueArgs& Cv, int row, int lane) {
+    const float* lg = Cv.logits + (int64_t)row * Cv.ldl;
+    const float* buckets = Cv.buckets;
+    const int NB = Cv.NB, H = Cv.H;
+    float* V = Cv.V; float* v_last = Cv.v_last;
     float mx = -3.0e38f;
     for (int i = lane; i < NB; i += 64) mx = fmaxf(mx, lg[i]);
     mx = group_max<64>(mx);
@@ -470,6 +467,15 @@ __global__ __launch_bounds__(256) void k_critic_value(const float* __restrict__ 
         V[row] = v;
         if (v_last && (row % H) == H - 1) v_last[row / H] = v;
     }
+}
+
+// Both row-wise head finishes in one launch: blockIdx.y = 0 -> reward / continue heads, 1 -> critic value.
+__global__ __launch_bounds__(256) void k_scalar_heads(const ScalarHeadsArgs P, const CriticValueArgs Cv) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= P.rows) return;
+    if (blockIdx.y == 0) scalar_heads_row(P, row, lane);
+    else critic_value_row(Cv, row, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1110,14 +1116,10 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             a.h[i] = ScalarHead{ws + wl.head[i][last & 1], M, m.ln_g[last], m.ln_b[last], m.head_w, m.head_b,
                                 i == 0 ? io->rewards_out : io->conts_out, nullptr, i == 0 ? 1 : 2};
         }
-        ProfScope prof(PC_SCALAR_HEADS, s, 4.0 * rows * M, 4.0 * (2.0 * rows * M + 6.0 * M + 2.0 * rows));
-        k_scalar_heads<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(a);
-        DRM_LAUNCH_CHECK();
-    }
-    {
-        ProfScope prof(PC_CRITIC_VALUE, s, 4.0 * rows * d.NB, 4.0 * ((double)rows * d.NB + d.NB + rows));
-        k_critic_value<<<dim3((rows + 3) / 4), dim3(256), 0, s>>>(ws + wl.critic_logits, 256, d.NB, w->buckets, rows, H,
-                                                                  io->values_out, io->v_last_out);
+        const CriticValueArgs cv{ws + wl.critic_logits, 256, d.NB, w->buckets, H, io->values_out, io->v_last_out};
+        ProfScope prof(PC_SCALAR_HEADS, s, 4.0 * rows * M + 4.0 * rows * d.NB,
+                       4.0 * (2.0 * rows * M + 6.0 * M + 2.0 * rows) + 4.0 * ((double)rows * d.NB + d.NB + rows));
+        k_scalar_heads<<<dim3((rows + 3) / 4, 2), dim3(256), 0, s>>>(a, cv);
         DRM_LAUNCH_CHECK();
     }
     return drm_lambda_return(io->rewards_out, io->conts_out, io->values_out, io->v_last_out, io->lam_returns_out, B, H,

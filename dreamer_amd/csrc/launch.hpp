@@ -28,11 +28,17 @@ static inline int check_problem(const ProblemSpec& s) {
     return DRM_OK;
 }
 
+constexpr int MID_MIN_ROWS = 96;
+
 static inline int launch_store(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents,
                         int classes, hipStream_t stream) {
     DRM_REQUIRE(np >= 1 && np <= MAX_PROBLEMS && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
     LinLaunch L{};
-    int tiles = 0;
+    int tiles = 0, kall = 0;
+    for (int i = 0; i < np; ++i) kall = specs[i].K > kall ? specs[i].K : kall;
+    // around a hundred rows and more: 32 x 32 output tiles per workgroup (one resident round, half the L2 reads)
+    const bool mid = M >= MID_MIN_ROWS && kall <= 512;
+    const int tw = mid ? 32 : 16;
     for (int i = 0; i < np; ++i) {
         if (int rc = check_problem(specs[i])) return rc;
         DRM_REQUIRE(!specs[i].tab || zidx, DRM_EINVAL, "gather table without indices");
@@ -41,7 +47,7 @@ static inline int launch_store(const ProblemSpec* specs, int np, int M, const ui
         p.W = specs[i].W; p.ldw = specs[i].ldw; p.bias = specs[i].bias; p.tab = specs[i].tab; p.ldt = specs[i].ldt;
         p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.tile_begin = tiles;
         p.add = specs[i].add; p.ldadd = specs[i].ldadd; p.rowscale = specs[i].rowscale; p.ldrs = specs[i].ldrs;
-        tiles += (specs[i].N + 15) / 16;
+        tiles += (specs[i].N + tw - 1) / tw;
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
     double fl = 0, by = 0;
@@ -54,6 +60,12 @@ static inline int launch_store(const ProblemSpec* specs, int np, int M, const ui
     int kmax = 0;
     for (int i = 0; i < np; ++i) kmax = specs[i].K > kmax ? specs[i].K : kmax;
     ProfScope prof(PC_LINEAR, stream, fl, by);
+    if (mid) {   // 48- or 32-row workgroups, whichever pads the row count less
+        if ((M + 47) / 48 * 48 <= (M + 31) / 32 * 32) k_linear16m<3, 2><<<dim3(tiles, (M + 47) / 48), dim3(256), 0, stream>>>(L);
+        else k_linear16m<2, 2><<<dim3(tiles, (M + 31) / 32), dim3(256), 0, stream>>>(L);
+        DRM_LAUNCH_CHECK();
+        return DRM_OK;
+    }
     const dim3 grid(tiles, (M + 15) / 16), block(256);
     switch (chunks_for(kmax)) {
         case 1: k_linear16<1, EPI_STORE, 1><<<grid, block, 0, stream>>>(L, GruEpilogue{}, SampleEpilogue{}, BwdEpilogue{}); break;

@@ -361,6 +361,191 @@ __global__ __launch_bounds__(256) void k_linear16(const LinLaunch L, const GruEp
     }
 }
 
+// Store-epilogue variant for a few hundred rows (K <= 512, one pass): one workgroup = (MT x 16) rows x
+// (NT x 16) columns.  Every A fragment feeds NT tiles and every B fragment MT tiles, so the L2 reads
+// per output drop by 2 MT NT / (MT + NT), and the grid (a quarter of the 16 x 16 form's at MT = NT = 2)
+// is resident in one round instead of queueing several latency-bound rounds per CU.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_linear16m(const LinLaunch L) {
+    __shared__ __attribute__((aligned(16))) float s_part[4][MT * NT][16][16];
+    __shared__ float s_red[2][4][MT * 16];
+    __shared__ uint8_t s_zi[MT * 16][MAX_LATENTS];
+
+    STAMP_DECL_AT((blockIdx.x == 0 && blockIdx.y == 0) || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))
+    STAMP();
+    int tile;
+    const LinProblem& P = pick_problem(L, blockIdx.x, tile);
+    const int m0 = blockIdx.y * (MT * 16), n0 = tile * (NT * 16);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int K = P.K;
+    const bool ln = P.ln_g != nullptr;
+
+    const float* xrow[MT];
+    const float* wrow[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xrow[i] = P.X + (int64_t)min(m0 + i * 16 + r, L.M - 1) * P.ldx + q * 8;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wrow[t] = P.W + (int64_t)min(n0 + t * 16 + r, P.N - 1) * P.ldw + q * 8;
+    if (P.tab != nullptr) {
+        for (int i = threadIdx.x; i < MT * 16 * L.latents; i += 256) {
+            const int row = i / L.latents, l = i - row * L.latents;
+            s_zi[row][l] = L.zidx[(int64_t)min(m0 + row, L.M - 1) * L.ldz + l];
+        }
+    }
+
+    // every load of the wave is issued before the first use of any of them
+    float a[4][MT][8], b[4][NT][8], g[4][8], e[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int kc = (c * 4 + wave) * 32;
+        if (kc < K) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) load8(xrow[i] + kc, a[c][i]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) load8(wrow[t] + kc, b[c][t]);
+            if (ln) { load8(P.ln_g + kc + q * 8, g[c]); load8(P.ln_b + kc + q * 8, e[c]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[c][i][j] = 0.f;
+        }
+    }
+#ifdef DRM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP();
+#endif
+    if (ln) {   // LayerNorm + SiLU of the producing layer on the A fragments (two-pass statistics per row)
+        float mean[MT], rstd[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm += a[c][i][j];
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (q == 0) s_red[0][wave][i * 16 + r] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rr = i * 16 + r;
+            mean[i] = ((s_red[0][0][rr] + s_red[0][1][rr]) + (s_red[0][2][rr] + s_red[0][3][rr])) / (float)K;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float d = a[c][i][j] - mean[i]; v += d * d; }
+                }
+            }
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) s_red[1][wave][rr] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int rr = i * 16 + r;
+            const float var = ((s_red[1][0][rr] + s_red[1][1][rr]) + (s_red[1][2][rr] + s_red[1][3][rr])) / (float)K;
+            rstd[i] = 1.0f / sqrtf(var + LN_EPS);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[c][i][j] = silu_f((a[c][i][j] - mean[i]) * rstd[i] * g[c][j] + e[c][j]);
+            }
+        }
+    }
+    STAMP();
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if ((c * 4 + wave) * 32 < K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i][j], b[c][t][j], acc[i][t], 0, 0, 0);
+        }
+    }
+    // split-K combine in a fixed order (C layout: row = 4*(lane>>4) + reg, col = lane & 15)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_part[wave][i * NT + t][q * 4 + j][r] = acc[i][t][j];
+    STAMP();
+    __syncthreads();
+    STAMP();
+    STAMP_FLUSH((unsigned long long)(5000 + (blockIdx.x == 0 ? 0 : 1)));
+
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    float y[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int it = i * NT + t, n = min(n0 + t * 16 + col, P.N - 1);
+            y[i][t] = ((s_part[0][it][row][col] + s_part[1][it][row][col]) + s_part[2][it][row][col]) + s_part[3][it][row][col];
+            y[i][t] += P.bias ? P.bias[n] : 0.f;
+        }
+    if (P.tab != nullptr) {
+        // one-hot rows of the table: the reads of a whole latent group for all of the thread's outputs are
+        // issued together (the table is cold in L2, and a dependent chain of small batches pays the miss
+        // latency once per batch)
+        for (int l0 = 0; l0 < L.latents; l0 += 16) {
+            float u[MT][NT][16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint8_t* zi = s_zi[i * 16 + row];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float* tb = P.tab + min(n0 + t * 16 + col, P.N - 1);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int l = min(l0 + k, L.latents - 1);
+                        u[i][t][k] = tb[(int64_t)(l * L.classes + zi[l]) * P.ldt];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) y[i][t] += (l0 + k < L.latents) ? u[i][t][k] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + i * 16 + row;
+        if (m >= L.M) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 16 + col;
+            if (n >= P.N) continue;
+            float v = y[i][t];
+            if (P.add != nullptr) v += P.add[(int64_t)m * P.ldadd + n];
+            if (P.rowscale != nullptr) v *= P.rowscale[(int64_t)m * P.ldrs];
+            P.Y[(int64_t)m * P.ldy + n] = v;
+        }
+    }
+}
+
 // CH (chunks of 32 per wave and pass) for a K: 1, 2 or 4; K > 512 takes several passes of 4
 inline int chunks_for(int K) { return K <= 128 ? 1 : (K <= 256 ? 2 : 4); }
 

@@ -1,5 +1,5 @@
 // Large-row linear block on fp32 MFMA (v_mfma_f32_32x32x2_f32): the MFMA-bound regime
-// (thousands of trajectories, BASELINE config 3).
+// (thousands of trajectories).
 //
 // Workgroup = 4 waves = a 64-row x 128-column output tile; waves are laid out 2 (rows) x 2 (columns),
 // each owning a 32 x 64 sub-tile = two 32x32 accumulators.  K is walked in steps of 32 through two LDS

@@ -1,4 +1,4 @@
-// Few-row linear block for the latency-bound regime (a handful of trajectories, BASELINE config 2).
+// Few-row linear block for the latency-bound regime (a handful of trajectories: the reference's default batch of 16).
 //
 // With 16 rows a 512 x 512 layer is 8 MFLOP against 1 MB of weights: nothing is compute-bound, and a
 // launch costs what its slowest workgroup needs to FETCH.  A CU sustains only a few tens of GB/s on

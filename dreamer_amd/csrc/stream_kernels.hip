@@ -245,3 +245,44 @@ extern "C" int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// two device-to-device copies in one launch (start-state staging of a graph-replayed block: the
+// recorded launches read fixed addresses, and each extra copy launch is a boundary on a path that
+// is a few hundred microseconds long)
+// ------------------------------------------------------------------------------------------------
+namespace drm {
+__global__ __launch_bounds__(256) void k_copy_pair(const uint8_t* __restrict__ a_src, uint8_t* __restrict__ a_dst, size_t a_bytes,
+                                                    const uint8_t* __restrict__ b_src, uint8_t* __restrict__ b_dst, size_t b_bytes,
+                                                    int vec) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    if (vec) {   // all pointers and sizes are multiples of 16
+        const size_t na = a_bytes / 16, nb = b_bytes / 16;
+        for (size_t i = tid; i < na + nb; i += step) {
+            if (i < na) reinterpret_cast<uint4*>(a_dst)[i] = reinterpret_cast<const uint4*>(a_src)[i];
+            else reinterpret_cast<uint4*>(b_dst)[i - na] = reinterpret_cast<const uint4*>(b_src)[i - na];
+        }
+    } else {
+        for (size_t i = tid; i < a_bytes + b_bytes; i += step) {
+            if (i < a_bytes) a_dst[i] = a_src[i];
+            else b_dst[i - a_bytes] = b_src[i - a_bytes];
+        }
+    }
+}
+}  // namespace drm
+
+extern "C" int drm_copy_pair(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
+                             drm_stream_t stream) {
+    DRM_REQUIRE((a_bytes == 0 || (a_src && a_dst)) && (b_bytes == 0 || (b_src && b_dst)), DRM_EINVAL, "null pointer");
+    if (a_bytes + b_bytes == 0) return DRM_OK;
+    const bool vec = aligned16(a_src) && aligned16(a_dst) && aligned16(b_src) && aligned16(b_dst) && a_bytes % 16 == 0 &&
+                     b_bytes % 16 == 0;
+    const size_t units = vec ? (a_bytes + b_bytes) / 16 : a_bytes + b_bytes;
+    size_t blocks = (units + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ProfScope prof(PC_ELEMENTWISE, (hipStream_t)stream, 0.0, 2.0 * (double)(a_bytes + b_bytes));
+    k_copy_pair<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+        (const uint8_t*)a_src, (uint8_t*)a_dst, a_bytes, (const uint8_t*)b_src, (uint8_t*)b_dst, b_bytes, vec ? 1 : 0);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}

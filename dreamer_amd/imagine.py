@@ -109,6 +109,15 @@ class ImagineEngine:
         return out
 
     @torch.no_grad()
+    def _noise_buffer(self, B: int, H: int):
+        """Action noise (H,B,A) and latent noise (H,B,L,K) as views of one buffer, so that a single
+        generator launch draws both (the same layout, hence the same stream, on every path)."""
+        d = self.dims
+        n_a, n_z = H * B * d.A, H * B * d.L * d.K
+        pad_a = (n_a + 63) // 64 * 64
+        flat = torch.empty(pad_a + n_z, device=self.device)
+        return flat, flat[:n_a].view(H, B, d.A), flat[pad_a:].view(H, B, d.L, d.K)
+
     def run(self, start: WorldModelState, horizon: int, gamma: float, lam: float,
             noise: Optional[Dict[str, torch.Tensor]] = None, forced_actions: Optional[torch.Tensor] = None,
             forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
@@ -128,26 +137,32 @@ class ImagineEngine:
         if slot is None:
             slot = {"out": self._alloc_outputs(B, H, *flags)}
             if persistent:
+                flat, ea, ez = self._noise_buffer(B, H)
                 slot.update(h0=torch.empty(B, d.D, device=dev), zidx0=torch.empty(B, d.L, dtype=torch.uint8, device=dev),
-                            ea=torch.empty(H, B, d.A, device=dev), ez=torch.empty(H, B, d.L, d.K, device=dev))
+                            noise=flat, ea=ea, ez=ez)
                 self._slots[(B, H, flags)] = slot
         out = slot["out"]
         h0 = start.h.detach()
         zidx0 = start_zidx if start_zidx is not None else N.onehot_to_index(start.z.detach().contiguous().float())
         if persistent:
-            slot["h0"].copy_(h0)
-            slot["zidx0"].copy_(zidx0)
+            if h0.dtype == torch.float32 and h0.is_contiguous() and zidx0.is_contiguous():
+                N.copy_pair(slot["h0"], h0, slot["zidx0"], zidx0)
+            else:
+                slot["h0"].copy_(h0)
+                slot["zidx0"].copy_(zidx0)
             h0, zidx0 = slot["h0"], slot["zidx0"]
             if noise is None:
-                ea, ez = slot["ea"].exponential_(), slot["ez"].exponential_()
+                slot["noise"].exponential_()
+                ea, ez = slot["ea"], slot["ez"]
             else:
                 ea, ez = slot["ea"].copy_(noise["a"]), slot["ez"].copy_(noise["z"])
         else:
             h0 = h0.contiguous().float()
             if noise is None:
-                noise = {"a": torch.empty(H, B, d.A, device=dev).exponential_(),
-                         "z": torch.empty(H, B, d.L, d.K, device=dev).exponential_()}
-            ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
+                flat, ea, ez = self._noise_buffer(B, H)
+                flat.exponential_()
+            else:
+                ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
         assert ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K)
         ws = self._workspace(B, H)
         io = N.drm_imagine_io()

@@ -267,7 +267,7 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
             current_obs, _ = env.reset()
         with torch.no_grad():
             obs_t = torch.as_tensor(np.asarray(current_obs), dtype=torch.float32, device=cfg.device).unsqueeze(0) / 255.0
-            model_state, _ = wm.step(model_state, last_action, obs_t, last_cont)
+            model_state = wm.act_step(model_state, last_action, obs_t, last_cont)   # the state of wm.step, heads skipped
             action = actor(model_state).sample().item()
         if updates_done == 0:
             action = env.action_space.sample()

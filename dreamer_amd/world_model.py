@@ -301,6 +301,31 @@ class WorldModel(nn.Module):
                 "x_hat": self.dec(h, z)}
         return WorldModelState(h=h, z=z), info
 
+    @torch.no_grad()
+    def act_step(self, state_prev: WorldModelState, a_prev_idx: torch.Tensor, x_cur: torch.Tensor,
+                 c_prev: Optional[torch.Tensor] = None) -> WorldModelState:
+        """Posterior state after one observed frame, without the heads and the decoder.
+
+        The acting loop keeps only the state of ``step`` (lib/trainer.py:126-130 discards the info dict), so
+        the prior, reward, continue and decoder evaluations are skipped here.  The generator is consumed as
+        in ``step``: the reset draw (only when ``c_prev`` is given), then the sample draw, (B,L,K) each.
+        On the GPU the recurrence runs through the fused scan kernels with T = 1.
+        """
+        from .observe import observe_scan
+        B = x_cur.shape[0]
+        L, K = self.num_latents, self.classes_per_latent
+        dev, dt = x_cur.device, x_cur.dtype
+        expo_z = torch.empty(1, B, L, K, device=dev, dtype=dt)
+        if c_prev is None:
+            expo_reset, c = expo_z.exponential_(), torch.ones(B, 1, device=dev, dtype=dt)   # c = 1: the reset draw is not used
+        else:
+            expo_reset, c = torch.empty(1, B, L, K, device=dev, dtype=dt).exponential_(), c_prev.reshape(B, 1).to(dt)
+            expo_z.exponential_()
+        fc = self.enc.fc[0]
+        n_conv = self.enc.conv_out_size
+        e_part = F.linear(self.enc.conv(x_cur), fc.weight[:, :n_conv], fc.bias).view(B, 1, L * K)
+        return observe_scan(self, e_part, a_prev_idx.reshape(B, 1), c, expo_reset, expo_z, state_prev)[3]
+
     # ------------------------------------------------------------------ loss terms
     def _kl_loss(self, q_logits: torch.Tensor, p_logits: torch.Tensor) -> torch.Tensor:
         lq = log_unimix(q_logits, self.unimix_eps, dim=-1)

@@ -96,6 +96,12 @@ int drm_sample_categorical_st(const float* logits, const float* expo, int64_t ro
 /* argmax over the last dim of a dense (rows,K) one-hot tensor -> uint8 indices. */
 int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint8_t* idx_out, drm_stream_t stream);
 
+/* Two device-to-device copies in one launch: staging of the start state (`start.h`, z indices of
+ * lib/trainer.py:178) into the fixed buffers a graph-replayed drm_imagine_block_f32 reads. Regions must
+ * not overlap. */
+int drm_copy_pair(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
+                  drm_stream_t stream);
+
 /* ---- fused linear block (building block of every step below) --------------------------------
  * Y[m, n] = bias[n] + sum_k f(X)[m,k] * W[n,k] + sum_l table[(l*classes + zidx[m,l]), n]
  *   f = identity, or SiLU(LayerNorm(X row; ln_gamma, ln_beta, eps 1e-5)) when ln_gamma != NULL

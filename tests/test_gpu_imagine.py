@@ -78,7 +78,7 @@ def test_teacher_forced_vs_oracle(B, H, layers):
 
 @pytest.mark.parametrize("B,H,D,M", [(6, 3, 1024, 768), (20, 2, 640, 1024), (260, 2, 1024, 544)])
 def test_wide_models_teacher_forced_vs_oracle(B, H, D, M):
-    """Widths beyond 512 (BASELINE config 5 scales the recurrent width) run on the large-row kernels for any batch."""
+    """Widths beyond 512 (a scaled-up recurrent width) run on the large-row kernels for any batch."""
     d = dict(DIMS["small"], D=D, M=M, L=6, A=5)
     salt = 500 + B
     wm, actor, critic = build_models(d, salt)
@@ -126,7 +126,7 @@ def test_bf16_matrix_inputs_within_bf16_tolerance():
 
 
 def test_large_batch_properties():
-    """B = 4096 trajectories (BASELINE config 3): rows are independent, so any slice of the batch
+    """B = 4096 trajectories (the large-batch case): rows are independent, so any slice of the batch
     must reproduce, bit for bit, what the same rows give when run alone."""
     d, salt, B, H = DIMS["default"], 5, 4096, 15
     wm, actor, critic, eng = _engine(d, salt)

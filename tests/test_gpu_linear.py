@@ -16,7 +16,8 @@ def _t(name, shape, scale=1.0, salt=0):
 
 
 @pytest.mark.parametrize("M,N_,K", [(16, 512, 512), (16, 1536, 512), (1, 6, 512), (5, 255, 64), (240, 512, 512),
-                                    (37, 70, 96), (16, 1024, 512), (4, 64, 64), (1000, 96, 128)])
+                                    (37, 70, 96), (16, 1024, 512), (4, 64, 64), (1000, 96, 128), (100, 70, 96), (130, 255, 320),
+                                    (97, 33, 512)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_linear_vs_torch(M, N_, K, ln):
     x = _t("x", (M, K), 2.0, M)
@@ -39,8 +40,9 @@ def test_asymmetric_identity_layout():
     assert torch.equal(y.cpu(), w[:, :16].T.contiguous())
 
 
-def test_linear_with_onehot_table_and_strided_weight():
-    M, D, L, K, Nn = 23, 128, 8, 32, 96
+@pytest.mark.parametrize("M", [23, 150])
+def test_linear_with_onehot_table_and_strided_weight(M):
+    D, L, K, Nn = 128, 8, 32, 96
     x = _t("x", (M, D))
     w_full = _t("w", (Nn, D + L * K), 0.05)          # Linear over cat[h, z_flat]
     b = _t("b", (Nn,), 0.1)

@@ -62,3 +62,31 @@ def test_scan_matches_host_eager_path_with_episode_boundaries():
             assert pg[name].grad is None, name
         else:
             assert rel_err(pg[name].grad.cpu(), p.grad) < 2e-4, name
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_act_step_runs_the_scan_kernels_and_matches_step(B):
+    """One acting step (B = 1 in the trainer) through the fused scan with T = 1 against the eager
+    ``step`` (lib/world_model.py:415-457) on the same generator state."""
+    wm, _, _ = build_models(DIMS["default"], 5)
+    wm = wm.to(DEV)
+    g = torch.Generator().manual_seed(B)
+    state = wm.init_state(B, device=DEV)
+    state.h.copy_(torch.randn(B, wm.hidden_size, generator=g).tanh())
+    x = torch.rand(B, 3, 64, 64, generator=g).to(DEV)
+    a = torch.randint(0, wm.action_size, (B,), generator=g).to(DEV)
+    c = torch.ones(B, 1, device=DEV)
+    c[B - 1] = 0.0
+    for _ in range(2):   # two consecutive steps: the second starts from a sampled state
+        with torch.no_grad():
+            torch.manual_seed(100 + B)
+            ref, _ = wm.step(state, a, x, c)
+            after_ref = torch.rand(4, device=DEV)
+            torch.manual_seed(100 + B)
+            got = wm.act_step(state, a, x, c)
+            after_got = torch.rand(4, device=DEV)
+        assert rel_err(got.h.cpu(), ref.h.cpu()) < TOL
+        assert torch.equal(got.z.argmax(-1), ref.z.argmax(-1))
+        assert torch.equal(got.z, (ref.z > 0.5).float())
+        assert torch.equal(after_ref, after_got)
+        state, c = got, torch.ones(B, 1, device=DEV)

@@ -142,3 +142,13 @@ def test_onehot_to_index():
     idx = torch.from_numpy((hash_uniform("oh", (777,), 1) * 32).astype(np.int64))
     z = torch.nn.functional.one_hot(idx, 32).float().to(DEV)
     assert torch.equal(N.onehot_to_index(z).cpu().long(), idx)
+
+
+@pytest.mark.parametrize("na,nb", [(16 * 512, 16 * 32), (5, 3), (4096 * 512, 4096 * 32), (0, 7)])
+def test_copy_pair_is_bit_exact(na, nb):
+    g = torch.Generator().manual_seed(na + nb)
+    a = torch.randn(na, generator=g).to(DEV)
+    b = torch.randint(0, 256, (nb,), generator=g, dtype=torch.uint8).to(DEV)
+    a_out, b_out = torch.full_like(a, -1.0), torch.zeros_like(b)
+    N.copy_pair(a_out, a, b_out, b)
+    assert torch.equal(a_out, a) and torch.equal(b_out, b)

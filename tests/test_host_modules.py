@@ -114,3 +114,29 @@ def test_replay_buffer_errors_and_bulk_store():
     assert (buf.idx, buf.full) == (one.idx, one.full)
     for name in ("observations", "actions", "rewards", "continues"):
         assert torch.equal(getattr(buf, name), getattr(one, name))
+
+
+@pytest.mark.parametrize("with_cont", [True, False])
+def test_act_step_is_the_state_of_step(with_cont):
+    """The acting shortcut returns the posterior state of ``step`` (lib/world_model.py:415-457) and leaves
+    the generator where ``step`` leaves it (reset draw, then sample draw)."""
+    from dreamer_amd.world_model import WorldModel
+    torch.manual_seed(3)
+    wm = WorldModel((3, 64, 64), 6, hidden_size=64, base_cnn_channels=4, mlp_hidden_units=32, num_latents=8,
+                    classes_per_latent=8)
+    B = 3
+    state = wm.init_state(B)
+    state.h.normal_()
+    x = torch.rand(B, 3, 64, 64)
+    a = torch.tensor([1, 5, 0])
+    c = torch.tensor([[1.0], [0.0], [1.0]]) if with_cont else None
+    with torch.no_grad():
+        torch.manual_seed(11)
+        ref, _ = wm.step(state, a, x, c)
+        after_ref = torch.rand(4)
+        torch.manual_seed(11)
+        got = wm.act_step(state, a, x, c)
+        after_got = torch.rand(4)
+    torch.testing.assert_close(got.h, ref.h, rtol=1e-5, atol=1e-6)
+    assert torch.equal(got.z, ref.z)
+    assert torch.equal(after_ref, after_got)

@@ -44,3 +44,13 @@ for kid, v in sorted(stats.items()):
           + " ".join(f"{np.median(a[:, i]):7.0f}" for i in range(1, a.shape[1])))
 for kid, v in sorted(xccs.items()):
     print("kernel", kid, "xcc of block 0 over launches:", v[:48])
+
+# raw time line around the last block's head launches (kernel ids 5000 / 5001 = first / last workgroup)
+idx = [i for i, r in enumerate(rec) if int(r[0]) in (5000, 5001)]
+if idx:
+    lo, hi = max(idx[-6] - 3, 0), min(idx[-1] + 4, len(rec))
+    base = rec[lo][2]
+    for r in rec[lo:hi]:
+        ns = int(r[1]) & 0xff
+        t = (r[2:2 + ns] - base) * 10.0
+        print(f"kid {int(r[0]):5d} xcc {(int(r[1]) >> 8) & 0xf}  stamps (ns from first shown): " + " ".join(f"{x:8.0f}" for x in t))
