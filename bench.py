@@ -64,7 +64,7 @@ def start_states(B, cfg, device, seed=1):
 
 
 # kernels (rocprofv3 names) behind each timing class of the library
-CLASS_KERNELS = {"linear": ("k_skinny", "k_linear16<1, 0"), "k_linear_big": ("k_linear_big",)}
+CLASS_KERNELS = {"linear": ("k_skinny", "k_linear16<1, 0", "k_linear16m"), "k_linear_big": ("k_linear_big",)}
 
 
 def pmc_traffic(workload, cls):
