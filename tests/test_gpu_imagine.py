@@ -45,9 +45,10 @@ def test_free_running_rollout_matches_reference(tag):
 
 
 @pytest.mark.parametrize("layers", [(1, 1), (3, 3), (2, 4)])
-@pytest.mark.parametrize("B,H", [(1, 1), (5, 3), (16, 15), (37, 4), (300, 3)])
-def test_teacher_forced_vs_oracle(B, H, layers):
-    d = dict(DIMS["small"], D=96, M=128, L=6, A=7)
+@pytest.mark.parametrize("B,H,A", [(1, 1, 7), (5, 3, 7), (16, 15, 7), (37, 4, 7), (300, 3, 7), (16, 3, 18), (100, 2, 18),
+                                   (260, 2, 18), (3, 2, 2)])
+def test_teacher_forced_vs_oracle(B, H, A, layers):
+    d = dict(DIMS["small"], D=96, M=128, L=6, A=A)   # A = 18: the full Atari action set
     salt = 100 + B + H
     wm, actor, critic = build_models(d, salt, actor_layers=layers[0], critic_layers=layers[1])
     ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
