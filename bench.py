@@ -164,7 +164,7 @@ def measure_train(device, world, rank, steps, warmup, fence):
     assert torch.isfinite(out["world_model_loss"]).all()
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ups = steps / dt
@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--train-steps", type=int, default=20, help="full training updates to time as well (0 = skip)")
+    ap.add_argument("--train-limit-s", type=float, default=240.0, help="give up on the training updates after this long")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,7 +273,7 @@ def main():
     assert torch.isfinite(out["lam_returns"]).all()
     progress(f"imagination block: {elapsed / args.steps * 1e3:.3f} ms per block on this rank")
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -320,17 +321,9 @@ def main():
                         kernels={k: {"us_per_step": v["ms_net"] * 1e3 / args.profile_steps,
                                      "launches_per_step": v["launches"] / args.profile_steps} for k, v in summ.items()})
 
-    train = None
-    if args.train_steps > 0:
-        progress("training updates: building the learner, warm-up (includes the convolution kernel search)")
-        try:
-            train = measure_train(device, world, rank, args.train_steps, 6, fence)
-            progress(f"training updates: {train['ms_per_update']:.2f} ms per update")
-        except Exception as e:  # the headline line above is already measured: report the failure beside it
-            train = {"error": f"{type(e).__name__}: {e}"}
-            progress(f"training updates failed: {train['error']}")
-
-    if rank == 0:
+    def emit(train):
+        if rank != 0:
+            return
         value = world * B * H * args.steps / elapsed
         line = {
             "metric": "imagined latent steps/sec", "value": value, "unit": "imagined latent steps/s", "n_gpus": world,
@@ -347,9 +340,39 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, wm, actor, critic, 16, H)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+
+    train = None
+    if args.train_steps > 0:
+        progress("training updates: building the learner, warm-up (includes the convolution kernel search)")
+        # The headline measurement is complete at this point.  If the training part stalls (a rank lost in a
+        # collective), every rank gives up after the limit and rank 0 still prints the line.
+        import threading
+
+        def give_up():
+            progress(f"training updates: no result after {args.train_limit_s} s, reporting without them")
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)   # where each rank is stuck
+            emit({"error": f"timeout after {args.train_limit_s} s"})
+            os._exit(0)
+
+        guard = threading.Timer(args.train_limit_s, give_up)
+        guard.daemon = True
+        guard.start()
+        try:
+            train = measure_train(device, world, rank, args.train_steps, 6, fence)
+            progress(f"training updates: {train['ms_per_update']:.2f} ms per update")
+        except Exception as e:  # the headline line above is already measured: report the failure beside it
+            train = {"error": f"{type(e).__name__}: {e}"}
+            progress(f"training updates failed: {train['error']}")
+        guard.cancel()
+
+    emit(train)
     if world > 1:
-        dist.destroy_process_group()
+        # every number is out; leave without the group's teardown, which would wait for a rank that failed
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -41,6 +41,21 @@ def init_from_env(device=None):
     return dev
 
 
+def _via_host(t: torch.Tensor) -> bool:
+    """gloo moves device tensors through the host itself, and not reliably for ranks that share a GPU
+    (the one-GPU rehearsal of the multi-process path): stage such tensors explicitly."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor) -> None:
+    if _via_host(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 class FlatGrads:
     """Flat gradient buffer of a module.
 
@@ -79,7 +94,7 @@ class FlatGrads:
         if self.flat is None:
             self._build()
         if world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            all_reduce_sum(self.flat)
             self.flat.div_(world_size())
 
 
@@ -94,7 +109,12 @@ def broadcast_module(module: torch.nn.Module, src: int = 0) -> None:
             by_dtype.setdefault(t.dtype, []).append(t.data)
         for tensors in by_dtype.values():
             flat = torch.cat([t.reshape(-1) for t in tensors])
-            dist.broadcast(flat, src=src)
+            if _via_host(flat):
+                h = flat.cpu()
+                dist.broadcast(h, src=src)
+                flat.copy_(h)
+            else:
+                dist.broadcast(flat, src=src)
             o = 0
             for t in tensors:
                 t.copy_(flat[o:o + t.numel()].view_as(t))
@@ -105,6 +125,11 @@ def gather_flat(x: torch.Tensor) -> torch.Tensor:
     """Concatenation over ranks of a flat tensor of equal length on every rank (rank order)."""
     if world_size() == 1:
         return x
+    if _via_host(x):
+        h = x.cpu().contiguous()
+        out = torch.empty(world_size() * h.numel(), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h)
+        return out.to(x.device)
     out = torch.empty(world_size() * x.numel(), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous())
     return out
