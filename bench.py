@@ -174,13 +174,25 @@ def measure_train(device, world, rank, steps, warmup, fence):
             "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}
 
 
-def measure_acting(learner, device, rng, steps=200):
+def measure_acting(learner, device, rng, steps=300):
     """Policy latency per environment step (lib/trainer.py:126-151): one 12 KB frame host -> device, the
-    B = 1 posterior step, the actor, and the action back on the host.  `full_step` evaluates the whole
-    `WorldModel.step` (prior, reward, continue and decoder heads too) as the reference's loop does."""
+    B = 1 posterior step, the actor, and the action back on the host.  `policy` is what `train` runs
+    (ActingPolicy: the step replayed from a recorded graph); `act_step` the same arithmetic launched
+    eagerly; `full_step` evaluates the whole `WorldModel.step` (prior, reward, continue and decoder heads
+    too) as the reference's loop does."""
+    from dreamer_amd.trainer import ActingPolicy
     wm, actor = learner.world_model, learner.actor
     frames = rng.integers(0, 256, size=(8, 3, 64, 64), dtype="uint8")
     out = {}
+    policy = ActingPolicy(wm, actor, device, (3, 64, 64))
+    for i in range(steps + 20):
+        if i == 20:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        policy.feedback(policy.act(frames[i % 8]), True)
+    torch.cuda.synchronize()
+    out["ms_per_env_step_policy"] = (time.perf_counter() - t0) / steps * 1e3
+    out["policy_graph"] = policy.graph is not None
     for name in ("act_step", "full_step"):
         state = wm.init_state(1, device)
         last_action = torch.zeros(1, dtype=torch.long, device=device)

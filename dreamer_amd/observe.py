@@ -155,17 +155,21 @@ class ObserveScanFn(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
-def observe_scan(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state):
-    """Returns (h (B,T,D), z (B,T,L,K), post_logits (B,T,L,K), last WorldModelState)."""
+def observe_scan(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state, engine_attr: str = "_observe_engine"):
+    """Returns (h (B,T,D), z (B,T,L,K), post_logits (B,T,L,K), last WorldModelState).
+
+    ``engine_attr`` names the attribute of ``wm`` that holds the packed tables and workspace; a caller
+    whose launches are recorded into a graph uses one of its own, so that no other caller ever
+    reallocates the buffers the recording points to."""
     if not e_part.is_cuda or state.h.size(-1) > 512:
         # host tensors, or a recurrent width beyond what the scan kernels are built for (D <= 512)
         return _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state)
     from . import _native as N
     from .world_model import WorldModelState
-    eng = getattr(wm, "_observe_engine", None)
+    eng = getattr(wm, engine_attr, None)
     if eng is None:
         eng = _ObserveEngine(wm)
-        object.__setattr__(wm, "_observe_engine", eng)
+        object.__setattr__(wm, engine_attr, eng)
     B, T = a_prev.shape
     L, K = wm.num_latents, wm.classes_per_latent
     g = wm.seq.gru

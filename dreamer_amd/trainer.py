@@ -31,7 +31,7 @@ from .config import Config
 from .critic import Critic
 from .imagine import imagine
 from .replay_buffer import ReplayBuffer
-from .utils import log_episode_video, log_wm_imagination_video, log_wm_reconstruction_video, make_env
+from .utils import log_episode_video, log_unimix, log_wm_imagination_video, log_wm_reconstruction_video, make_env
 from .world_model import WorldModel, WorldModelState
 
 
@@ -102,6 +102,87 @@ class _GraphedUpdate:
         if self.g_step is None:
             self._capture_step([p for p in self.grads.params])
         self.g_step.replay()
+
+
+class ActingPolicy:
+    """The policy side of the environment loop (lib/trainer.py:126-151): frame -> posterior state ->
+    action, with the recurrent state, the previous action and the continue flag kept on the device.
+
+    On the GPU the whole step (u8 -> f32, encoder, fused scan step, actor, action draw, state update) is
+    recorded once into a HIP graph after a few eager steps and replayed per environment step; per step
+    the host copies one 12 KB frame in and reads one index back.  The graph reads the parameters in
+    place, so optimiser steps between replays are seen (DRM_NO_ACT_GRAPH=1 keeps the step eager).
+    """
+
+    def __init__(self, world_model: WorldModel, actor: Actor, device, obs_shape):
+        self.wm, self.actor = world_model, actor
+        self.device = torch.device(device)
+        on_gpu = self.device.type == "cuda"
+        self.use_graph = on_gpu and os.environ.get("DRM_NO_ACT_GRAPH", "0") != "1"
+        self.frame = torch.zeros(1, *obs_shape, dtype=torch.uint8, device=self.device)
+        self.stage = torch.zeros(1, *obs_shape, dtype=torch.uint8, pin_memory=True) if on_gpu else None
+        self.h = torch.zeros(1, world_model.hidden_size, device=self.device)
+        self.z = torch.zeros(1, world_model.num_latents, world_model.classes_per_latent, device=self.device)
+        self.last_action = torch.zeros(1, dtype=torch.long, device=self.device)
+        self.last_cont = torch.ones(1, 1, dtype=torch.float32, device=self.device)
+        self.action = torch.zeros(1, dtype=torch.long, device=self.device)
+        self.graph = None
+        self.eager_steps = 0
+        self.reset()
+
+    @property
+    def state(self) -> WorldModelState:
+        return WorldModelState(h=self.h, z=self.z)
+
+    @torch.no_grad()
+    def reset(self) -> None:
+        """Start of an episode (lib/trainer.py:145-148): fresh state, previous action 0, continue 1."""
+        s = self.wm.init_state(1, self.device)
+        self.h.copy_(s.h)
+        self.z.copy_(s.z)
+        self.last_action.zero_()
+        self.last_cont.fill_(1.0)
+
+    @torch.no_grad()
+    def _step(self) -> None:
+        obs = self.frame.to(torch.float32) / 255.0
+        s = self.wm.act_step(self.state, self.last_action, obs, self.last_cont)
+        x = torch.cat([s.h, s.z.reshape(1, -1)], dim=-1)
+        logits = self.actor.head(self.actor.mlp(x))
+        # Categorical(logits=log_unimix(...)).sample() of lib/trainer.py:130, i.e. multinomial's
+        # argmax(probs / Exp(1)), without the distribution object's host-side argument checks
+        probs = torch.softmax(log_unimix(logits, self.actor.unimix_eps, dim=-1), dim=-1)
+        self.action.copy_(torch.argmax(probs / torch.empty_like(probs).exponential_(), dim=-1))
+        self.h.copy_(s.h)
+        self.z.copy_(s.z)
+
+    @torch.no_grad()
+    def act(self, obs) -> int:
+        """Action index for the frame ``obs`` (uint8 array of the observation shape)."""
+        frame = torch.as_tensor(np.asarray(obs), dtype=torch.uint8)
+        if self.stage is not None:
+            self.stage.copy_(frame.reshape(self.stage.shape))
+            self.frame.copy_(self.stage, non_blocking=True)
+        else:
+            self.frame.copy_(frame.reshape(self.frame.shape))
+        if self.use_graph and self.eager_steps >= 3:
+            if self.graph is None:   # recording launches nothing: the step itself is the replay below
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._step()
+            self.graph.replay()
+        else:
+            self._step()
+            self.eager_steps += 1
+        return int(self.action.item())
+
+    def feedback(self, action: int, cont: bool) -> None:
+        """What the environment did with the step: the action actually taken and whether the episode goes on."""
+        self.last_action.fill_(int(action))
+        self.last_cont.fill_(float(cont))
+        if not cont:
+            self.reset()
 
 
 class Learner:
@@ -258,30 +339,21 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
     time_counter = time.time()
     update_credit, credits_per_update = 0.0, cfg.batch_size * cfg.batch_length
     updates_done = update_counter = policy_steps = 0
-    model_state = wm.init_state(1, cfg.device)
-    last_action = torch.zeros(1, dtype=torch.long, device=cfg.device)
-    last_cont = torch.ones(1, dtype=torch.float32, device=cfg.device)
+    policy = ActingPolicy(wm, actor, cfg.device, obs_shape)
     current_obs = None
     for _ in range(cfg.num_iterations):
         if current_obs is None:
             current_obs, _ = env.reset()
-        with torch.no_grad():
-            obs_t = torch.as_tensor(np.asarray(current_obs), dtype=torch.float32, device=cfg.device).unsqueeze(0) / 255.0
-            model_state = wm.act_step(model_state, last_action, obs_t, last_cont)   # the state of wm.step, heads skipped
-            action = actor(model_state).sample().item()
+        action = policy.act(current_obs)
         if updates_done == 0:
             action = env.action_space.sample()
         next_obs, reward, terminated, truncated, _ = env.step(action)
         cont = not (terminated or truncated)
         buffer.store(current_obs, action, float(reward), cont)
         current_obs = next_obs
-        last_action.fill_(action)
-        last_cont.fill_(float(cont))
+        policy.feedback(action, cont)
         if not cont:
             current_obs, _ = env.reset()
-            model_state = wm.init_state(1, cfg.device)
-            last_action.zero_()
-            last_cont.fill_(1.0)
         policy_steps += 1
         update_credit += cfg.train_ratio
 

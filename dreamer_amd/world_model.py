@@ -324,7 +324,8 @@ class WorldModel(nn.Module):
         fc = self.enc.fc[0]
         n_conv = self.enc.conv_out_size
         e_part = F.linear(self.enc.conv(x_cur), fc.weight[:, :n_conv], fc.bias).view(B, 1, L * K)
-        return observe_scan(self, e_part, a_prev_idx.reshape(B, 1), c, expo_reset, expo_z, state_prev)[3]
+        return observe_scan(self, e_part, a_prev_idx.reshape(B, 1), c, expo_reset, expo_z, state_prev,
+                            engine_attr="_observe_engine_act")[3]
 
     # ------------------------------------------------------------------ loss terms
     def _kl_loss(self, q_logits: torch.Tensor, p_logits: torch.Tensor) -> torch.Tensor:

@@ -48,3 +48,43 @@ def test_graph_replayed_updates_match_eager(monkeypatch):
         for k in pe:
             assert torch.allclose(pg[k], pe[k], rtol=1e-4, atol=1e-6), (name, k)
     assert torch.allclose(graphed.actor.ret_scale.p95, eager.actor.ret_scale.p95, rtol=1e-5)
+
+
+def test_acting_policy_graph_replay_matches_eager_steps(monkeypatch):
+    """The recorded policy step (frame -> posterior state -> action) against the same step launched
+    eagerly: same generator state -> same actions and states, also after the parameters changed in place."""
+    import numpy as np
+    from dreamer_amd.config import Config
+    from dreamer_amd.trainer import ActingPolicy, Learner
+    cfg = Config(device=torch.device("cuda:0"))
+    frames = np.random.default_rng(3).integers(0, 256, size=(12, 3, 64, 64), dtype=np.uint8)
+
+    def run(graph):
+        monkeypatch.setenv("DRM_NO_ACT_GRAPH", "0" if graph else "1")
+        torch.manual_seed(5)
+        learner = Learner(cfg, (3, 64, 64), 6)
+        with torch.no_grad():
+            torch.nn.init.normal_(learner.actor.head.weight, std=0.5)
+        policy = ActingPolicy(learner.world_model, learner.actor, cfg.device, (3, 64, 64))
+        torch.manual_seed(9)
+        policy.reset()
+        acts, hs = [], []
+        for i in range(12):
+            if i == 8:   # an optimiser step between two environment steps
+                with torch.no_grad():
+                    for p in learner.world_model.seq.parameters():
+                        p.mul_(1.01)
+                    for p in learner.actor.parameters():
+                        p.mul_(0.97)
+            a = policy.act(frames[i])
+            policy.feedback(a, i != 5)   # one episode boundary
+            acts.append(a)
+            hs.append(policy.h.clone())
+        return policy, acts, torch.stack(hs)
+
+    pe, ae, he = run(False)
+    pg, ag, hg = run(True)
+    assert pe.graph is None and pg.graph is not None
+    assert ae == ag
+    assert float((he - hg).abs().max()) < 1e-5
+    assert len(set(ae)) > 1
