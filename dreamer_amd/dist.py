@@ -65,10 +65,14 @@ class FlatGrads:
     straight into the buffer.
     """
 
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, static: bool = False):
         self.module = module
         self.flat: Optional[torch.Tensor] = None
+        self.flat_params: Optional[torch.Tensor] = None
         self.params: List[torch.nn.Parameter] = []
+        self.offsets: List[int] = []
+        if static:
+            self._build_static()
 
     def _build(self) -> None:
         self.params = [p for p in self.module.parameters() if p.grad is not None]
@@ -80,7 +84,27 @@ class FlatGrads:
             view = self.flat[o:o + p.numel()].view_as(p)
             view.copy_(p.grad)
             p.grad = view
+            self.offsets.append(o)
             o += p.numel()
+
+    def _build_static(self) -> None:
+        """Flat buffers for the gradients AND the parameters of every trainable parameter, laid out
+        before the first step (each tensor starts on a 256-byte boundary): what a flat optimiser step
+        needs.  Parameters that never receive a gradient keep a zero gradient, which leaves them unchanged."""
+        self.params = [p for p in self.module.parameters() if p.requires_grad]
+        ref = self.params[0]
+        o = 0
+        for p in self.params:
+            self.offsets.append(o)
+            o += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(o, dtype=ref.dtype, device=ref.device)
+        self.flat_params = torch.zeros(o, dtype=ref.dtype, device=ref.device)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                pv = self.flat_params[off:off + p.numel()].view_as(p)
+                pv.copy_(p.data)
+                p.data = pv
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero(self) -> None:
         if self.flat is None:

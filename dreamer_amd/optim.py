@@ -1,0 +1,63 @@
+"""Adam over the flat parameter / gradient buffers of ``dist.FlatGrads`` (GPU only).
+
+Replaces ``clip_grad_norm_`` + ``torch.optim.Adam(fused=True).step()`` of the reference's update
+(lib/trainer.py:95-103, :170-173, :231-235, :244-247) by two HBM-bound launches of the native library;
+the arithmetic is torch's (global-norm clip coefficient min(1, c / (norm + 1e-6)); Adam without weight
+decay, bias corrections from the step count).  ``state_dict`` has torch's layout, so checkpoints keep the
+reference's format.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from .dist import FlatGrads
+
+
+class FlatAdam:
+    def __init__(self, grads: FlatGrads, lr: float, eps: float, clip: float, betas=(0.9, 0.999)):
+        if grads.flat_params is None:
+            raise ValueError("FlatAdam needs FlatGrads(module, static=True)")
+        self.grads, self.lr, self.eps, self.clip, self.betas = grads, float(lr), float(eps), float(clip), betas
+        flat = grads.flat
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self._ws = torch.empty(N.lib().drm_adam_workspace_bytes() // 4, dtype=torch.float32, device=flat.device)
+
+    def step(self) -> None:
+        """Clip by global norm, then one Adam step; gradients stay unscaled in the buffer."""
+        g = self.grads
+        N.check(N.lib().drm_adam_flat_step(g.flat_params.data_ptr(), g.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), g.flat.numel(), self.lr, self.betas[0], self.betas[1],
+                                           self.eps, self.clip, self.step_count.data_ptr(), self._ws.data_ptr(),
+                                           self.grad_norm.data_ptr(), N.stream_ptr(g.flat.device)), "drm_adam_flat_step")
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.grads.zero()
+
+    def state_dict(self):
+        """torch.optim.Adam's layout over the parameters of the flat buffer, in order."""
+        g = self.grads
+        state = {}
+        for i, (p, off) in enumerate(zip(g.params, g.offsets)):
+            sl = slice(off, off + p.numel())
+            state[i] = {"step": self.step_count.reshape(()).clone(), "exp_avg": self.exp_avg[sl].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": True, "differentiable": False, "fused": True,
+                 "decoupled_weight_decay": False, "params": list(range(len(g.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd) -> None:
+        g = self.grads
+        for i, (p, off) in enumerate(zip(g.params, g.offsets)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            sl = slice(off, off + p.numel())
+            self.exp_avg[sl].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_count.fill_(float(st["step"]))

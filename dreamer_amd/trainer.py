@@ -30,6 +30,7 @@ from .actor import Actor
 from .config import Config
 from .critic import Critic
 from .imagine import imagine
+from .optim import FlatAdam
 from .replay_buffer import ReplayBuffer
 from .utils import log_episode_video, log_unimix, log_wm_imagination_video, log_wm_reconstruction_video, make_env
 from .world_model import WorldModel, WorldModelState
@@ -38,6 +39,14 @@ from .world_model import WorldModel, WorldModelState
 def _adam(params, lr, eps, capturable=False):
     params = list(params)
     return torch.optim.Adam(params, lr=lr, eps=eps, fused=params[0].is_cuda, capturable=capturable and params[0].is_cuda)
+
+
+def _clip_and_step(optim, params, clip: float) -> None:
+    if isinstance(optim, FlatAdam):
+        optim.step()          # the clip is part of the flat step
+    else:
+        nn.utils.clip_grad_norm_(params, clip)
+        optim.step()
 
 
 class _GraphedUpdate:
@@ -92,8 +101,7 @@ class _GraphedUpdate:
     def _capture_step(self, params) -> None:
         self.g_step = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_step):
-            nn.utils.clip_grad_norm_(params, self.clip)
-            self.optim.step()
+            _clip_and_step(self.optim, params, self.clip)
             if self.post is not None:
                 self.post()
 
@@ -207,12 +215,21 @@ class Learner:
         for m in (self.world_model, self.actor, self.critic):
             D.broadcast_module(m)
         self.actor.ret_scale.gather = D.gather_flat if D.world_size() > 1 else None
-        self.optim_world_model = _adam(self.world_model.parameters(), cfg.world_model_lr, cfg.world_model_adam_eps,
-                                       capturable=torch.device(dev).type == "cuda")
         on_gpu = torch.device(dev).type == "cuda"
-        self.optim_actor = _adam(self.actor.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
-        self.optim_critic = _adam(self.critic.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
-        self.g_wm, self.g_actor, self.g_critic = D.FlatGrads(self.world_model), D.FlatGrads(self.actor), D.FlatGrads(self.critic)
+        # GPU: parameters and gradients of each model in flat buffers, optimiser step = the library's flat
+        # clip + Adam (DRM_TORCH_ADAM=1: torch's fused Adam on the same parameters)
+        flat_adam = on_gpu and os.environ.get("DRM_TORCH_ADAM", "0") != "1"
+        self.g_wm, self.g_actor, self.g_critic = (D.FlatGrads(m, static=flat_adam)
+                                                  for m in (self.world_model, self.actor, self.critic))
+        if flat_adam:
+            self.optim_world_model = FlatAdam(self.g_wm, cfg.world_model_lr, cfg.world_model_adam_eps, cfg.world_model_grad_clip)
+            self.optim_actor = FlatAdam(self.g_actor, cfg.actor_critic_lr, cfg.actor_critic_adam_eps, cfg.actor_critic_grad_clip)
+            self.optim_critic = FlatAdam(self.g_critic, cfg.actor_critic_lr, cfg.actor_critic_adam_eps, cfg.actor_critic_grad_clip)
+        else:
+            self.optim_world_model = _adam(self.world_model.parameters(), cfg.world_model_lr, cfg.world_model_adam_eps,
+                                           capturable=on_gpu)
+            self.optim_actor = _adam(self.actor.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
+            self.optim_critic = _adam(self.critic.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
         # actor / critic updates replayed from HIP graphs after a few eager ones (DRM_NO_UPDATE_GRAPHS=1: always eager)
         self.graph_updates = on_gpu and os.environ.get("DRM_NO_UPDATE_GRAPHS", "0") != "1"
         self.eager_updates = 0
@@ -234,7 +251,9 @@ class Learner:
         self.g_wm.zero()
         wm_loss.backward()
         self.g_wm.sync()
-        if self.graph_updates and self.eager_updates >= 3:
+        if isinstance(self.optim_world_model, FlatAdam):
+            self.optim_world_model.step()          # two launches: nothing to gain from a recorded graph
+        elif self.graph_updates and self.eager_updates >= 3:
             self._wm_graph.step_only()
         else:
             nn.utils.clip_grad_norm_(self.world_model.parameters(), cfg.world_model_grad_clip)
@@ -259,16 +278,14 @@ class Learner:
         self.g_critic.zero()
         critic_loss.backward()
         self.g_critic.sync()
-        nn.utils.clip_grad_norm_(self.critic.parameters(), cfg.actor_critic_grad_clip)
-        self.optim_critic.step()
+        _clip_and_step(self.optim_critic, self.critic.parameters(), cfg.actor_critic_grad_clip)
         self.critic.update_slow()
         # ---- actor ----
         actor_loss = self.actor.loss(model_states=Hs, actions=actions, returns=returns, values=values)
         self.g_actor.zero()
         actor_loss.backward()
         self.g_actor.sync()
-        nn.utils.clip_grad_norm_(self.actor.parameters(), cfg.actor_critic_grad_clip)
-        self.optim_actor.step()
+        _clip_and_step(self.optim_actor, self.actor.parameters(), cfg.actor_critic_grad_clip)
         return {"world_model_loss": wm_loss.detach(), "actor_loss": actor_loss.detach(), "critic_loss": critic_loss.detach(),
                 "pred_loss": wm_info["pred_loss"].detach(), "dyn_loss": wm_info["dyn_loss"].detach(),
                 "rep_loss": wm_info["rep_loss"].detach(), "imagination": im}

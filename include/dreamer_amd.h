@@ -96,6 +96,18 @@ int drm_sample_categorical_st(const float* logits, const float* expo, int64_t ro
 /* argmax over the last dim of a dense (rows,K) one-hot tensor -> uint8 indices. */
 int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint8_t* idx_out, drm_stream_t stream);
 
+/* Optimiser step on flat buffers: global-norm clip (torch.nn.utils.clip_grad_norm_, coefficient
+ * min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clip) followed by Adam without weight decay, the
+ * arithmetic of torch's fused Adam (lib/trainer.py:95-103 creates the optimisers, :170-173, :231-235,
+ * :244-247 clip and step them).  `params`, `grads`, `exp_avg`, `exp_avg_sq`: n floats each, 16-byte aligned.
+ * `step`: one device float holding the number of steps taken so far (incremented by the call).
+ * `workspace`: drm_adam_workspace_bytes() bytes.  `norm_out` (optional): receives the gradient norm.
+ * Gradients are left unscaled.  Two launches, no host synchronisation: recordable into a graph. */
+size_t drm_adam_workspace_bytes(void);
+int drm_adam_flat_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                       double beta1, double beta2, double eps, double max_norm, float* step, float* workspace,
+                       float* norm_out, drm_stream_t stream);
+
 /* Two device-to-device copies in one launch: staging of the start state (`start.h`, z indices of
  * lib/trainer.py:178) into the fixed buffers a graph-replayed drm_imagine_block_f32 reads. Regions must
  * not overlap. */

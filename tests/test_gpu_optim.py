@@ -1,0 +1,68 @@
+"""Flat clip + Adam step of the native library against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused)
+(the optimiser calls of lib/trainer.py:95-103, :170-173) on the same gradients."""
+import pytest
+import torch
+import torch.nn as nn
+
+from dreamer_amd.dist import FlatGrads
+from dreamer_amd.optim import FlatAdam
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(37, 129), nn.LayerNorm(129), nn.SiLU(), nn.Linear(129, 5), nn.Embedding(7, 3)).to(DEV)
+
+
+@pytest.mark.parametrize("clip,scale", [(1000.0, 1.0), (0.5, 1.0), (100.0, 50.0)])
+def test_flat_adam_matches_torch_fused_adam(clip, scale):
+    ref, mine = _model(1), _model(1)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-8, fused=True)
+    grads = FlatGrads(mine, static=True)
+    opt = FlatAdam(grads, lr=3e-4, eps=1e-8, clip=clip)
+    assert all(p.data_ptr() % 256 == 0 for p in mine.parameters())
+    g = torch.Generator(device=DEV).manual_seed(7)
+    for step in range(6):
+        opt_ref.zero_grad(set_to_none=False)
+        grads.zero()
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            gr = torch.randn(pr.shape, device=DEV, generator=g) * scale * (0.0 if step == 3 and pr.dim() == 1 else 1.0)
+            pr.grad = gr.clone()
+            pm.grad.copy_(gr)
+        norm_ref = nn.utils.clip_grad_norm_(ref.parameters(), clip)
+        opt_ref.step()
+        opt.step()
+        assert abs(float(opt.grad_norm) - float(norm_ref)) <= 1e-5 * float(norm_ref)
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            err = float((pr - pm).abs().max())
+            assert err <= 2e-6 * max(float(pr.abs().max()), 1e-3) + 1e-9, (step, err)
+    sd_ref, sd = opt_ref.state_dict(), opt.state_dict()
+    assert sd["param_groups"][0]["params"] == sd_ref["param_groups"][0]["params"]
+    for i in sd_ref["state"]:
+        assert float(sd["state"][i]["step"]) == float(sd_ref["state"][i]["step"]) == 6.0
+        for key in ("exp_avg", "exp_avg_sq"):
+            a, b = sd["state"][i][key], sd_ref["state"][i][key]
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+
+
+def test_flat_adam_in_a_recorded_graph():
+    m = _model(2)
+    grads = FlatGrads(m, static=True)
+    opt = FlatAdam(grads, lr=1e-3, eps=1e-8, clip=10.0)
+    ref = _model(2)
+    opt_ref = FlatAdam(FlatGrads(ref, static=True), lr=1e-3, eps=1e-8, clip=10.0)
+    graph = torch.cuda.CUDAGraph()
+    grads.flat.normal_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        opt.step()
+    for i in range(4):
+        gr = torch.randn_like(grads.flat)
+        grads.flat.copy_(gr)
+        opt_ref.grads.flat.copy_(gr)
+        graph.replay()
+        opt_ref.step()
+    assert float(opt.step_count) == float(opt_ref.step_count) == 4.0
+    assert torch.equal(grads.flat_params, opt_ref.grads.flat_params)
