@@ -168,7 +168,7 @@ def measure_train(device, world, rank, steps, warmup, fence):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ups = steps / dt
-    acting = measure_acting(learner, device, rng)
+    acting = None if os.environ.get("DRM_BENCH_NO_ACTING", "0") == "1" else measure_acting(learner, device, rng)
     return {"acting": acting, "updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
             "replayed_steps_per_sec": ups * world * cfg.batch_size * cfg.batch_length, "steps": steps, "warmup": warmup,
             "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}

@@ -71,6 +71,7 @@ class FlatGrads:
         self.flat_params: Optional[torch.Tensor] = None
         self.params: List[torch.nn.Parameter] = []
         self.offsets: List[int] = []
+        self.static = False
         if static:
             self._build_static()
 
@@ -90,7 +91,11 @@ class FlatGrads:
     def _build_static(self) -> None:
         """Flat buffers for the gradients AND the parameters of every trainable parameter, laid out
         before the first step (each tensor starts on a 256-byte boundary): what a flat optimiser step
-        needs.  Parameters that never receive a gradient keep a zero gradient, which leaves them unchanged."""
+        needs.  In this mode backward writes ordinary ``.grad`` tensors (``zero()`` drops them, so autograd
+        hands over each gradient without an accumulation kernel per parameter) and ``sync()`` gathers them
+        into the flat buffer with one multi-tensor copy.  Parameters that receive no gradient keep a
+        zero slot, which leaves them unchanged."""
+        self.static = True
         self.params = [p for p in self.module.parameters() if p.requires_grad]
         ref = self.params[0]
         o = 0
@@ -99,24 +104,37 @@ class FlatGrads:
             o += (p.numel() + 63) // 64 * 64
         self.flat = torch.zeros(o, dtype=ref.dtype, device=ref.device)
         self.flat_params = torch.zeros(o, dtype=ref.dtype, device=ref.device)
+        self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
+        self._missing = None
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
                 pv = self.flat_params[off:off + p.numel()].view_as(p)
                 pv.copy_(p.data)
                 p.data = pv
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero(self) -> None:
-        if self.flat is None:
+        if self.flat is None or self.static:
             for p in self.module.parameters():
                 p.grad = None
         else:
             self.flat.zero_()
 
+    def _gather(self) -> None:
+        have = [i for i, p in enumerate(self.params) if p.grad is not None]
+        missing = frozenset(range(len(self.params))) - frozenset(have)
+        if missing != self._missing:   # slots of parameters without a gradient hold zeros
+            for i in missing:
+                self.views[i].zero_()
+            self._missing = missing
+        with torch.no_grad():
+            torch._foreach_copy_([self.views[i] for i in have], [self.params[i].grad for i in have])
+
     def sync(self) -> None:
         """Average the gradients over the data-parallel ranks (no-op for a single process)."""
         if self.flat is None:
             self._build()
+        if self.static:
+            self._gather()
         if world_size() > 1:
             all_reduce_sum(self.flat)
             self.flat.div_(world_size())
