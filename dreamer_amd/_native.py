@@ -106,6 +106,12 @@ SIGNATURES = {
     "drm_sample_categorical_st": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_onehot_to_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "drm_kl_pair_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    "drm_kl_pair_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float]
+                             + [C.c_void_p] * 5),
+    "drm_mse_rows_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "drm_mse_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_adam_workspace_bytes": (C.c_size_t, []),
     "drm_adam_flat_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 5 + [C.c_void_p] * 4),
     "drm_copy_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

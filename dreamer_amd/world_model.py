@@ -385,11 +385,22 @@ class WorldModel(nn.Module):
         hf, zf = h.reshape(B * T, -1), z.reshape(B * T, L, K)
         prior = self.dyn(hf)
         postf = post.reshape(B * T, L, K)
-        pred = self._prediction_loss(obs.reshape(B * T, *obs.shape[2:]), self.dec(hf, zf),
-                                     rewards.reshape(B * T, 1), self.rew(hf, zf),
-                                     continues.to(obs.dtype).reshape(B * T, 1), self.cont(hf, zf)).mean()
-        dyn = self._dynamics_loss(postf, prior).mean()
-        rep = self._representation_loss(postf, prior).mean()
+        x_true, x_hat = obs.reshape(B * T, *obs.shape[2:]), self.dec(hf, zf)
+        from . import losses as FL
+        if FL.fused_ok(postf, K) and x_hat.numel() // (B * T) % 4 == 0:
+            # the same terms from the library's row kernels (one launch each way instead of the eager chains)
+            image = FL.mse_rows(x_hat, x_true)
+            reward = 0.5 * (self.rew(hf, zf) - symlog(rewards.reshape(B * T, 1))).pow(2).mean(dim=-1)
+            cont = F.binary_cross_entropy_with_logits(self.cont(hf, zf), continues.to(obs.dtype).reshape(B * T, 1),
+                                                      reduction="none").squeeze(-1)
+            pred = (image + reward + cont).mean()
+            dyn_rows, rep_rows = FL.kl_pair(postf, prior, self.unimix_eps, self.free_bits / float(L))
+            dyn, rep = dyn_rows.mean(), rep_rows.mean()
+        else:
+            pred = self._prediction_loss(x_true, x_hat, rewards.reshape(B * T, 1), self.rew(hf, zf),
+                                         continues.to(obs.dtype).reshape(B * T, 1), self.cont(hf, zf)).mean()
+            dyn = self._dynamics_loss(postf, prior).mean()
+            rep = self._representation_loss(postf, prior).mean()
         total = self.beta_pred * pred + self.beta_dyn * dyn + self.beta_rep * rep
         return total, {"total_loss": total, "pred_loss": pred, "dyn_loss": dyn, "rep_loss": rep, "state": last,
                        "h": h, "post_logits": post, "prior_logits": prior.view(B, T, L, K)}

@@ -96,6 +96,23 @@ int drm_sample_categorical_st(const float* logits, const float* expo, int64_t ro
 /* argmax over the last dim of a dense (rows,K) one-hot tensor -> uint8 indices. */
 int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint8_t* idx_out, drm_stream_t stream);
 
+/* KL terms of the world-model loss (lib/world_model.py:463-475, :501-528) over `rows` x L categoricals of
+ * K = 32 classes: row value = sum_l max(KL(unimix(post_l) || unimix(prior_l)), free_nats). The dynamics
+ * and the representation loss share the value (dyn_out, rep_out: `rows` floats each, both written) and
+ * differ in the gradient: backward takes the upstream gradient of each use (g_dyn flows to the prior
+ * logits only, g_rep to the posterior logits only; either may be NULL) and writes d_post, d_prior. */
+int drm_kl_pair_forward(const float* post, const float* prior, int64_t rows, int32_t L, int32_t K, float unimix_eps,
+                        float free_nats, float* dyn_out, float* rep_out, drm_stream_t stream);
+int drm_kl_pair_backward(const float* post, const float* prior, int64_t rows, int32_t L, int32_t K, float unimix_eps,
+                         float free_nats, const float* g_dyn, const float* g_rep, float* d_post, float* d_prior,
+                         drm_stream_t stream);
+
+/* Image term of the prediction loss (lib/world_model.py:483-487): out[r] = 0.5 * mean_e (x_hat[r,e] - x[r,e])^2
+ * over frames of E floats (E % 4 == 0); backward: d_x_hat[r,e] = g[r] * (x_hat - x) / E. */
+int drm_mse_rows_forward(const float* x_hat, const float* x, int64_t rows, int32_t E, float* out, drm_stream_t stream);
+int drm_mse_rows_backward(const float* x_hat, const float* x, int64_t rows, int32_t E, const float* g, float* d_x_hat,
+                          drm_stream_t stream);
+
 /* Optimiser step on flat buffers: global-norm clip (torch.nn.utils.clip_grad_norm_, coefficient
  * min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clip) followed by Adam without weight decay, the
  * arithmetic of torch's fused Adam (lib/trainer.py:95-103 creates the optimisers, :170-173, :231-235,
