@@ -99,9 +99,9 @@ SIGNATURES = {
     "drm_prof_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "drm_lambda_return": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
-    "drm_ln_silu_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "drm_ln_silu_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "drm_ln_silu_slices": (C.c_int32, [C.c_int64, C.c_int32]),
-    "drm_ln_silu_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p]),
+    "drm_ln_silu_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_seq_gather": (C.c_int, [C.POINTER(drm_ring), C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "drm_sample_categorical_st": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -203,31 +203,42 @@ def seq_gather(obs, actions, rewards, continues, starts, T: int, want_f32: bool 
     return o, a, r, c, f
 
 
-def ln_silu_forward(x, gamma, beta, eps: float):
-    """y = SiLU(LayerNorm over each whole sample (x viewed as (N, E)); returns y, mean (N), rstd (N)."""
+def ln_silu_forward(x, gamma, beta, eps: float, channel_bias=None):
+    """y = SiLU(LayerNorm over each whole sample of x (+ channel_bias[c]), x viewed as (N, E)); returns y, mean (N), rstd (N)."""
     require_cuda(x, gamma, beta)
     _dense(x, torch.float32, "x"); _dense(gamma, torch.float32, "gamma"); _dense(beta, torch.float32, "beta")
     N, E = x.shape[0], gamma.numel()
+    hw = 0
+    if channel_bias is not None:
+        _dense(channel_bias, torch.float32, "channel_bias")
+        hw = E // channel_bias.numel()
     y = torch.empty_like(x)
     mean = torch.empty(N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N, dtype=torch.float32, device=x.device)
     check(lib().drm_ln_silu_forward(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                    rstd.data_ptr(), N, E, float(eps), stream_ptr(x.device)), "drm_ln_silu_forward")
+                                    rstd.data_ptr(), N, E, float(eps), ptr(channel_bias), hw, stream_ptr(x.device)),
+          "drm_ln_silu_forward")
     return y, mean, rstd
 
 
-def ln_silu_backward(x, dy, gamma, beta, mean, rstd):
-    """dx and [d gamma; d beta] (2, E) of ln_silu_forward."""
+def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None):
+    """dx and [d gamma; d beta] (2, E) of ln_silu_forward; with a channel bias a third result, d bias (C)."""
     require_cuda(x, dy, gamma, beta, mean, rstd)
     _dense(x, torch.float32, "x"); _dense(dy, torch.float32, "dy")
     N, E = x.shape[0], gamma.numel()
     slices = lib().drm_ln_silu_slices(N, E)
     dx = torch.empty_like(x)
-    part = torch.empty((slices, 2, E), dtype=torch.float32, device=x.device)
+    rows = 2 if channel_bias is None else 3
+    part = torch.empty((slices, rows, E), dtype=torch.float32, device=x.device)
+    sums = None if channel_bias is None else torch.empty(2 * N, dtype=torch.float32, device=x.device)
+    hw = 0 if channel_bias is None else E // channel_bias.numel()
     check(lib().drm_ln_silu_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                                     rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, stream_ptr(x.device)),
-          "drm_ln_silu_backward")
-    return dx, part.sum(0)
+                                     rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, ptr(channel_bias), hw, ptr(sums),
+                                     stream_ptr(x.device)), "drm_ln_silu_backward")
+    total = part.sum(0)
+    if channel_bias is None:
+        return dx, total
+    return dx, total[:2], total[2].view(channel_bias.numel(), hw).sum(1)
 
 
 def sample_categorical_st(logits, expo, unimix_eps: Optional[float], want_z=True, want_idx=True, want_y=False):

@@ -11,6 +11,11 @@
 // the statistics and the output pass, so x (and dy) are read once.  The parameter gradients are a
 // reduction over samples: a second kernel walks the samples with one thread per four elements and
 // writes one partial row per sample slice (no atomics; the caller adds the slices).
+//
+// Optional channel bias: the producing convolution's bias b[c] (c = e / (H*W)) is added on the way in
+// (x + b is what gets normalised), so the convolution runs without its own bias pass over the output;
+// its gradient, the sum of dx over samples and positions, comes out of the parameter kernel as a third
+// partial row per slice (dx is re-formed there from two per-sample sums the dx kernel leaves behind).
 #include "common.hpp"
 
 namespace drm {
@@ -32,7 +37,7 @@ template <int NV>
 __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_fwd(const float* __restrict__ X, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ Y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int E, float eps) {
+                                                            int E, float eps, const float* __restrict__ cbias, int hw) {
     __shared__ float s16[16];
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_fwd(const float* __restr
     for (int i = 0; i < NV; ++i) {
         const int e = (i * LNS_THREADS + tid) * 4;
         v[i] = e < E ? *reinterpret_cast<const float4*>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cbias != nullptr && e < E) { const float b = cbias[e / hw]; v[i].x += b; v[i].y += b; v[i].z += b; v[i].w += b; }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = block_sum_1024(s, s16) / (float)E;
@@ -82,7 +88,8 @@ template <int NV>
 __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __restrict__ X, const float* __restrict__ dY,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                               float* __restrict__ dX, int E) {
+                                                               float* __restrict__ dX, int E, const float* __restrict__ cbias, int hw,
+                                                               float* __restrict__ sums_out) {
     __shared__ float s16[16];
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -93,10 +100,11 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __re
     for (int i = 0; i < NV; ++i) {
         const int e = (i * LNS_THREADS + tid) * 4;
         if (e < E) {
-            const float4 xv = *reinterpret_cast<const float4*>(X + n * E + e);
+            float4 xv = *reinterpret_cast<const float4*>(X + n * E + e);
             const float4 dy = *reinterpret_cast<const float4*>(dY + n * E + e);
             const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
             const float4 be = *reinterpret_cast<const float4*>(beta + e);
+            if (cbias != nullptr) { const float b = cbias[e / hw]; xv.x += b; xv.y += b; xv.z += b; xv.w += b; }
             xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
             g[i].x = dsilu_times(dy.x, xh[i].x * ga.x + be.x) * ga.x;
             g[i].y = dsilu_times(dy.y, xh[i].y * ga.y + be.y) * ga.y;
@@ -111,6 +119,7 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __re
     }
     const float mg = block_sum_1024(sg, s16) / (float)E;
     const float mgx = block_sum_1024(sgx, s16) / (float)E;
+    if (sums_out != nullptr && tid == 0) { sums_out[2 * n] = mg; sums_out[2 * n + 1] = mgx; }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = (i * LNS_THREADS + tid) * 4;
@@ -129,26 +138,37 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __re
 __global__ __launch_bounds__(256) void k_lnsilu_bwd_params(const float* __restrict__ X, const float* __restrict__ dY,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                           float* __restrict__ part, int N, int E, int per_slice) {
+                                                           float* __restrict__ part, int N, int E, int per_slice,
+                                                           const float* __restrict__ cbias, int hw, const float* __restrict__ sums) {
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= E) return;
+    const float cb = cbias != nullptr ? cbias[e / hw] : 0.f;
+    float4 dxs = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n0 = blockIdx.y * per_slice, n1 = min(n0 + per_slice, N);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
     const float4 be = *reinterpret_cast<const float4*>(beta + e);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
     for (int n = n0; n < n1; ++n) {
         const float mean = mean_in[n], rstd = rstd_in[n];
-        const float4 xv = *reinterpret_cast<const float4*>(X + (int64_t)n * E + e);
+        float4 xv = *reinterpret_cast<const float4*>(X + (int64_t)n * E + e);
         const float4 dy = *reinterpret_cast<const float4*>(dY + (int64_t)n * E + e);
+        xv.x += cb; xv.y += cb; xv.z += cb; xv.w += cb;
         const float x0 = (xv.x - mean) * rstd, x1 = (xv.y - mean) * rstd, x2 = (xv.z - mean) * rstd, x3 = (xv.w - mean) * rstd;
         const float d0 = dsilu_times(dy.x, x0 * ga.x + be.x), d1 = dsilu_times(dy.y, x1 * ga.y + be.y);
         const float d2 = dsilu_times(dy.z, x2 * ga.z + be.z), d3 = dsilu_times(dy.w, x3 * ga.w + be.w);
         dg.x += d0 * x0; dg.y += d1 * x1; dg.z += d2 * x2; dg.w += d3 * x3;
         db.x += d0; db.y += d1; db.z += d2; db.w += d3;
+        if (cbias != nullptr) {   // dx of this sample, as the dx kernel formed it
+            const float mg = sums[2 * n], mgx = sums[2 * n + 1];
+            dxs.x += rstd * (d0 * ga.x - mg - x0 * mgx); dxs.y += rstd * (d1 * ga.y - mg - x1 * mgx);
+            dxs.z += rstd * (d2 * ga.z - mg - x2 * mgx); dxs.w += rstd * (d3 * ga.w - mg - x3 * mgx);
+        }
     }
-    float* row = part + (int64_t)blockIdx.y * 2 * E;
+    const int rows = cbias != nullptr ? 3 : 2;
+    float* row = part + (int64_t)blockIdx.y * rows * E;
     *reinterpret_cast<float4*>(row + e) = dg;
     *reinterpret_cast<float4*>(row + E + e) = db;
+    if (cbias != nullptr) *reinterpret_cast<float4*>(row + 2 * E + e) = dxs;
 }
 
 static int lns_check(int64_t N, int E, const void* a, const void* b, const void* c) {
@@ -163,16 +183,18 @@ static int lns_check(int64_t N, int E, const void* a, const void* b, const void*
 using namespace drm;
 
 extern "C" int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                   int64_t N, int32_t E, float eps, drm_stream_t stream) {
+                                   int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, drm_stream_t stream) {
     if (int rc = lns_check(N, E, x, gamma, beta)) return rc;
     DRM_REQUIRE(y && mean && rstd && aligned16(y), DRM_EINVAL, "null or misaligned output");
+    DRM_REQUIRE(!channel_bias || (hw >= 4 && hw % 4 == 0 && E % hw == 0), DRM_EINVAL, "channel bias needs hw %% 4 == 0 and E %% hw == 0");
+    const float* cb = channel_bias;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PC_ELEMENTWISE, s, 14.0 * N * E, 8.0 * N * E + 8.0 * E);
     const dim3 grid((unsigned)N), block(LNS_THREADS);
-    if (E <= 4096) k_lnsilu_fwd<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
-    else if (E <= 8192) k_lnsilu_fwd<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
-    else if (E <= 16384) k_lnsilu_fwd<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
-    else k_lnsilu_fwd<8><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps);
+    if (E <= 4096) k_lnsilu_fwd<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
+    else if (E <= 8192) k_lnsilu_fwd<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
+    else if (E <= 16384) k_lnsilu_fwd<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
+    else k_lnsilu_fwd<8><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -188,25 +210,29 @@ extern "C" int32_t drm_ln_silu_slices(int64_t N, int32_t E) {
 
 extern "C" int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                                     const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E,
-                                    drm_stream_t stream) {
+                                    const float* channel_bias, int32_t hw, float* sample_sums, drm_stream_t stream) {
     if (int rc = lns_check(N, E, x, gamma, beta)) return rc;
+    DRM_REQUIRE(!channel_bias || (hw >= 4 && hw % 4 == 0 && E % hw == 0 && sample_sums), DRM_EINVAL,
+                "channel bias needs hw %% 4 == 0, E %% hw == 0 and the per-sample sums buffer");
+    const float* cb = channel_bias;
+    if (!cb) sample_sums = nullptr;
     DRM_REQUIRE(dy && mean && rstd && dx && param_partials && aligned16(dy) && aligned16(dx) && aligned16(param_partials),
                 DRM_EINVAL, "null or misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)N), block(LNS_THREADS);
     {
         ProfScope prof(PC_ELEMENTWISE, s, 30.0 * N * E, 12.0 * N * E + 8.0 * E);
-        if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
-        else if (E <= 8192) k_lnsilu_bwd_dx<2><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
-        else if (E <= 16384) k_lnsilu_bwd_dx<4><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
-        else k_lnsilu_bwd_dx<8><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E);
+        if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
+        else if (E <= 8192) k_lnsilu_bwd_dx<2><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
+        else if (E <= 16384) k_lnsilu_bwd_dx<4><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
+        else k_lnsilu_bwd_dx<8><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
         DRM_LAUNCH_CHECK();
     }
     const int slices = drm_ln_silu_slices(N, E);
     const int per_slice = (int)((N + slices - 1) / slices);
     ProfScope prof(PC_ELEMENTWISE, s, 24.0 * N * E, 8.0 * N * E + 8.0 * slices * E);
     k_lnsilu_bwd_params<<<dim3((E / 4 + 255) / 256, slices), dim3(256), 0, s>>>(x, dy, gamma, beta, mean, rstd, param_partials,
-                                                                                 (int)N, E, per_slice);
+                                                                                 (int)N, E, per_slice, cb, hw, sample_sums);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

@@ -124,29 +124,45 @@ class _ConvTranspose2d(nn.ConvTranspose2d):
 
 
 class _LayerNormSiLUFn(torch.autograd.Function):
-    """nn.LayerNorm([C, H, W]) followed by nn.SiLU as one HIP kernel forward and two backward."""
+    """nn.LayerNorm([C, H, W]) followed by nn.SiLU as one HIP kernel forward and two backward; with
+    ``cbias`` the bias of the convolution that produced ``x`` is added inside the same kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, cbias=None):
         from . import _native as N
         x = x.contiguous()
-        y, mean, rstd = N.ln_silu_forward(x, weight, bias, eps)
-        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        y, mean, rstd = N.ln_silu_forward(x, weight, bias, eps, cbias)
+        ctx.save_for_backward(x, weight, bias, mean, rstd, cbias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import _native as N
-        x, weight, bias, mean, rstd = ctx.saved_tensors
-        dx, dparams = N.ln_silu_backward(x, dy.contiguous(), weight, bias, mean, rstd)
-        return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None
+        x, weight, bias, mean, rstd, cbias = ctx.saved_tensors
+        if cbias is None:
+            dx, dparams = N.ln_silu_backward(x, dy.contiguous(), weight, bias, mean, rstd)
+            return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None, None
+        dx, dparams, dcb = N.ln_silu_backward(x, dy.contiguous(), weight, bias, mean, rstd, cbias)
+        return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None, dcb
+
+
+def _conv_no_bias(mod, x):
+    if isinstance(mod, nn.ConvTranspose2d):
+        return F.conv_transpose2d(x, mod.weight, None, mod.stride, mod.padding, mod.output_padding, mod.groups, mod.dilation)
+    return F.conv2d(x, mod.weight, None, mod.stride, mod.padding, mod.dilation, mod.groups)
 
 
 class _Tower(nn.Sequential):
-    """nn.Sequential whose (LayerNorm over the whole sample, SiLU) pairs run fused on the GPU; the
-    modules, and therefore the state-dict keys, are those of the plain Sequential."""
+    """nn.Sequential whose (LayerNorm over the whole sample, SiLU) pairs run fused on the GPU, together
+    with the bias of the convolution in front of them; the modules, and therefore the state-dict keys,
+    are those of the plain Sequential."""
 
     fuse = os.environ.get("DRM_NO_LN_FUSION", "0") != "1"
+
+    @staticmethod
+    def _fusable(m, nxt, shape, x):
+        return (isinstance(m, nn.LayerNorm) and isinstance(nxt, nn.SiLU) and x.dtype == torch.float32 and len(shape) == 4
+                and tuple(m.normalized_shape) == tuple(shape[1:]) and m.weight.numel() % 4 == 0 and m.weight.numel() <= 32768)
 
     def forward(self, x):
         mods = list(self)
@@ -155,9 +171,16 @@ class _Tower(nn.Sequential):
             return super().forward(x)
         while i < len(mods):
             m = mods[i]
-            if (isinstance(m, nn.LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.SiLU) and x.is_cuda
-                    and x.dtype == torch.float32 and x.dim() == 4 and tuple(m.normalized_shape) == tuple(x.shape[1:])
-                    and m.weight.numel() % 4 == 0 and m.weight.numel() <= 32768):
+            if (isinstance(m, (_Conv2d, _ConvTranspose2d)) and m.bias is not None and i + 2 < len(mods)
+                    and isinstance(mods[i + 1], nn.LayerNorm) and x.dim() == 4 and x.dtype == torch.float32):
+                ln = mods[i + 1]
+                shape = (x.shape[0],) + tuple(ln.normalized_shape)
+                hw = shape[2] * shape[3] if len(shape) == 4 else 0
+                if self._fusable(ln, mods[i + 2], shape, x) and hw % 4 == 0 and shape[1] == m.out_channels:
+                    x = _LayerNormSiLUFn.apply(_conv_no_bias(m, x), ln.weight, ln.bias, ln.eps, m.bias)
+                    i += 3
+                    continue
+            if i + 1 < len(mods) and self._fusable(m, mods[i + 1], tuple(x.shape), x):
                 x = _LayerNormSiLUFn.apply(x, m.weight, m.bias, m.eps)
                 i += 2
             else:

@@ -332,12 +332,18 @@ int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io,
  *   forward : y = SiLU((x - mean_n) * rstd_n * gamma + beta), biased variance, rstd = 1/sqrt(var + eps);
  *             mean, rstd (N) are saved for the backward pass.
  *   backward: dx (N, E), and param_partials (slices, 2, E) whose sum over the first axis is
- *             [d gamma; d beta] (slices = drm_ln_silu_slices(N, E); no atomics are used). */
+ *             [d gamma; d beta] (slices = drm_ln_silu_slices(N, E); no atomics are used).
+ * channel_bias (optional, C = E / hw floats, hw = H*W a multiple of 4): the bias of the convolution that
+ * produced x (nn.Conv2d / nn.ConvTranspose2d bias of the same stage) is added on the way in, i.e. the
+ * block computes SiLU(LayerNorm(x + b[c])) and the convolution runs without its bias pass.  Backward then
+ * needs sample_sums (2N floats, scratch) and writes param_partials (slices, 3, E); the third row summed
+ * over slices and over the hw positions of a channel is d b[c]. */
 int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int64_t N, int32_t E, float eps, drm_stream_t stream);
+                        int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, drm_stream_t stream);
 int32_t drm_ln_silu_slices(int64_t N, int32_t E);
 int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
-                         const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E, drm_stream_t stream);
+                         const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E,
+                         const float* channel_bias, int32_t hw, float* sample_sums, drm_stream_t stream);
 
 #ifdef __cplusplus
 }

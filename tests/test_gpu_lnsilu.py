@@ -25,3 +25,40 @@ def test_matches_torch_layer_norm_silu(N, shape):
     assert rel(out, ref) < 2e-6
     assert rel(hx, gx) < 1e-5
     assert rel(hw, gw) < 1e-5 and rel(hb, gb) < 1e-5
+
+
+@pytest.mark.parametrize("N,C,HW", [(64, 32, (32, 32)), (9, 8, (4, 4)), (130, 16, (8, 8)), (3, 4, (2, 2))])
+def test_channel_bias_variant_matches_bias_add_then_layer_norm_silu(N, C, HW):
+    """SiLU(LayerNorm(x + b[c])) with the producing convolution's bias folded into the kernels, and its gradient."""
+    g = torch.Generator().manual_seed(N + C)
+    shape = (C, *HW)
+    x = (torch.randn(N, *shape, generator=g) * 1.3).to(DEV).requires_grad_(True)
+    w = (1.0 + 0.2 * torch.randn(*shape, generator=g)).to(DEV).requires_grad_(True)
+    b = (0.1 * torch.randn(*shape, generator=g)).to(DEV).requires_grad_(True)
+    cb = (0.5 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    dy = torch.randn(N, *shape, generator=g).to(DEV)
+    ref = F.silu(F.layer_norm(x + cb.view(1, C, 1, 1), shape, w, b, 1e-5))
+    gx, gw, gb, gc = torch.autograd.grad(ref, (x, w, b, cb), dy)
+    out = _LayerNormSiLUFn.apply(x, w, b, 1e-5, cb)
+    hx, hw, hb, hc = torch.autograd.grad(out, (x, w, b, cb), dy)
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / (r.double().abs().max() + 1e-30))
+    assert rel(out, ref) < 2e-6
+    assert rel(hx, gx) < 1e-5 and rel(hw, gw) < 1e-5 and rel(hb, gb) < 1e-5
+    assert rel(hc, gc) < 5e-5   # a sum of N*H*W values that largely cancel
+
+
+def test_tower_with_folded_conv_bias_matches_plain_sequential(monkeypatch):
+    from dreamer_amd import world_model as W
+    torch.manual_seed(4)
+    enc = W.Encoder((3, 64, 64), base_cnn_channels=8).to(DEV)
+    x = torch.rand(6, 3, 64, 64, device=DEV)
+    monkeypatch.setattr(W._Tower, "fuse", False)
+    ref = enc.conv(x)
+    g_ref = torch.autograd.grad(ref.square().sum(), list(enc.conv.parameters()))
+    monkeypatch.setattr(W._Tower, "fuse", True)
+    out = enc.conv(x)
+    g_out = torch.autograd.grad(out.square().sum(), list(enc.conv.parameters()))
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / (r.double().abs().max() + 1e-30))
+    assert rel(out, ref) < 1e-5
+    for (name, _), a, r in zip(enc.conv.named_parameters(), g_out, g_ref):
+        assert rel(a, r) < 2e-4, name
