@@ -159,6 +159,7 @@ def measure_train(device, world, rank, steps, warmup, fence):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
+    host_dt = time.perf_counter() - t0     # launches queued; the GPU may still be working
     fence()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out["world_model_loss"]).all()
@@ -169,7 +170,7 @@ def measure_train(device, world, rank, steps, warmup, fence):
         dt = float(t.item())
     ups = steps / dt
     acting = None if os.environ.get("DRM_BENCH_NO_ACTING", "0") == "1" else measure_acting(learner, device, rng)
-    return {"acting": acting, "updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
+    return {"acting": acting, "host_ms_per_update": host_dt / steps * 1e3, "updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
             "replayed_steps_per_sec": ups * world * cfg.batch_size * cfg.batch_length, "steps": steps, "warmup": warmup,
             "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}
 

@@ -221,23 +221,26 @@ def ln_silu_forward(x, gamma, beta, eps: float, channel_bias=None):
     return y, mean, rstd
 
 
-def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None):
-    """dx and [d gamma; d beta] (2, E) of ln_silu_forward; with a channel bias a third result, d bias (C)."""
+def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None, want_dx_sum=False):
+    """dx and [d gamma; d beta] (2, E) of ln_silu_forward; with a channel bias a third result, d bias (C);
+    with ``want_dx_sum`` a third result sum_n dx[n] (E)."""
     require_cuda(x, dy, gamma, beta, mean, rstd)
     _dense(x, torch.float32, "x"); _dense(dy, torch.float32, "dy")
     N, E = x.shape[0], gamma.numel()
     slices = lib().drm_ln_silu_slices(N, E)
     dx = torch.empty_like(x)
-    rows = 2 if channel_bias is None else 3
+    rows = 2 if (channel_bias is None and not want_dx_sum) else 3
     part = torch.empty((slices, rows, E), dtype=torch.float32, device=x.device)
-    sums = None if channel_bias is None else torch.empty(2 * N, dtype=torch.float32, device=x.device)
+    sums = None if rows == 2 else torch.empty(2 * N, dtype=torch.float32, device=x.device)
     hw = 0 if channel_bias is None else E // channel_bias.numel()
     check(lib().drm_ln_silu_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, ptr(channel_bias), hw, ptr(sums),
                                      stream_ptr(x.device)), "drm_ln_silu_backward")
     total = part.sum(0)
-    if channel_bias is None:
+    if rows == 2:
         return dx, total
+    if channel_bias is None:
+        return dx, total[:2], total[2]
     return dx, total[:2], total[2].view(channel_bias.numel(), hw).sum(1)
 
 

@@ -134,6 +134,102 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __re
     }
 }
 
+// ---- the same two kernels for short samples (rows of an MLP, E <= 2048): one wave per sample, four
+// samples per workgroup, no LDS and no barrier ------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void k_lnsilu_row_fwd(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ Y,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                        int64_t N, int E, float eps, const float* __restrict__ cbias, int hw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * 64 + lane) * 4;
+        v[i] = e < E ? *reinterpret_cast<const float4*>(X + n * E + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cbias != nullptr && e < E) { const float b = cbias[e / hw]; v[i].x += b; v[i].y += b; v[i].z += b; v[i].w += b; }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = group_sum<64>(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((i * 64 + lane) * 4 < E) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<64>(q) / (float)E + eps);
+    if (lane == 0) { mean_out[n] = mean; rstd_out[n] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * 64 + lane) * 4;
+        if (e < E) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + e);
+            const float4 b = *reinterpret_cast<const float4*>(beta + e);
+            float4 o;
+            o.x = silu_f((v[i].x - mean) * rstd * g.x + b.x);
+            o.y = silu_f((v[i].y - mean) * rstd * g.y + b.y);
+            o.z = silu_f((v[i].z - mean) * rstd * g.z + b.z);
+            o.w = silu_f((v[i].w - mean) * rstd * g.w + b.w);
+            *reinterpret_cast<float4*>(Y + n * E + e) = o;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_lnsilu_row_bwd_dx(const float* __restrict__ X, const float* __restrict__ dY,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           float* __restrict__ dX, int64_t N, int E, const float* __restrict__ cbias,
+                                                           int hw, float* __restrict__ sums_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float mean = mean_in[n], rstd = rstd_in[n];
+    float4 xh[NV], g[NV];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * 64 + lane) * 4;
+        if (e < E) {
+            float4 xv = *reinterpret_cast<const float4*>(X + n * E + e);
+            const float4 dy = *reinterpret_cast<const float4*>(dY + n * E + e);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
+            const float4 be = *reinterpret_cast<const float4*>(beta + e);
+            if (cbias != nullptr) { const float b = cbias[e / hw]; xv.x += b; xv.y += b; xv.z += b; xv.w += b; }
+            xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+            g[i].x = dsilu_times(dy.x, xh[i].x * ga.x + be.x) * ga.x;
+            g[i].y = dsilu_times(dy.y, xh[i].y * ga.y + be.y) * ga.y;
+            g[i].z = dsilu_times(dy.z, xh[i].z * ga.z + be.z) * ga.z;
+            g[i].w = dsilu_times(dy.w, xh[i].w * ga.w + be.w) * ga.w;
+            sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            sgx += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        } else {
+            xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = xh[i];
+        }
+    }
+    const float mg = group_sum<64>(sg) / (float)E;
+    const float mgx = group_sum<64>(sgx) / (float)E;
+    if (sums_out != nullptr && lane == 0) { sums_out[2 * n] = mg; sums_out[2 * n + 1] = mgx; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = (i * 64 + lane) * 4;
+        if (e < E) {
+            float4 o;
+            o.x = rstd * (g[i].x - mg - xh[i].x * mgx);
+            o.y = rstd * (g[i].y - mg - xh[i].y * mgx);
+            o.z = rstd * (g[i].z - mg - xh[i].z * mgx);
+            o.w = rstd * (g[i].w - mg - xh[i].w * mgx);
+            *reinterpret_cast<float4*>(dX + n * E + e) = o;
+        }
+    }
+}
+
 // grid (ceil(E / 1024), slices): thread = four elements, walks the samples of its slice
 __global__ __launch_bounds__(256) void k_lnsilu_bwd_params(const float* __restrict__ X, const float* __restrict__ dY,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -158,17 +254,17 @@ __global__ __launch_bounds__(256) void k_lnsilu_bwd_params(const float* __restri
         const float d2 = dsilu_times(dy.z, x2 * ga.z + be.z), d3 = dsilu_times(dy.w, x3 * ga.w + be.w);
         dg.x += d0 * x0; dg.y += d1 * x1; dg.z += d2 * x2; dg.w += d3 * x3;
         db.x += d0; db.y += d1; db.z += d2; db.w += d3;
-        if (cbias != nullptr) {   // dx of this sample, as the dx kernel formed it
+        if (sums != nullptr) {   // dx of this sample, as the dx kernel formed it
             const float mg = sums[2 * n], mgx = sums[2 * n + 1];
             dxs.x += rstd * (d0 * ga.x - mg - x0 * mgx); dxs.y += rstd * (d1 * ga.y - mg - x1 * mgx);
             dxs.z += rstd * (d2 * ga.z - mg - x2 * mgx); dxs.w += rstd * (d3 * ga.w - mg - x3 * mgx);
         }
     }
-    const int rows = cbias != nullptr ? 3 : 2;
+    const int rows = sums != nullptr ? 3 : 2;
     float* row = part + (int64_t)blockIdx.y * rows * E;
     *reinterpret_cast<float4*>(row + e) = dg;
     *reinterpret_cast<float4*>(row + E + e) = db;
-    if (cbias != nullptr) *reinterpret_cast<float4*>(row + 2 * E + e) = dxs;
+    if (sums != nullptr) *reinterpret_cast<float4*>(row + 2 * E + e) = dxs;
 }
 
 static int lns_check(int64_t N, int E, const void* a, const void* b, const void* c) {
@@ -190,6 +286,15 @@ extern "C" int drm_ln_silu_forward(const float* x, const float* gamma, const flo
     const float* cb = channel_bias;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PC_ELEMENTWISE, s, 14.0 * N * E, 8.0 * N * E + 8.0 * E);
+    if (E <= 2048) {   // short samples: one wave each
+        const dim3 rgrid((unsigned)((N + 3) / 4)), rblock(256);
+        if (E <= 256) k_lnsilu_row_fwd<1><<<rgrid, rblock, 0, s>>>(x, gamma, beta, y, mean, rstd, N, E, eps, cb, hw);
+        else if (E <= 512) k_lnsilu_row_fwd<2><<<rgrid, rblock, 0, s>>>(x, gamma, beta, y, mean, rstd, N, E, eps, cb, hw);
+        else if (E <= 1024) k_lnsilu_row_fwd<4><<<rgrid, rblock, 0, s>>>(x, gamma, beta, y, mean, rstd, N, E, eps, cb, hw);
+        else k_lnsilu_row_fwd<8><<<rgrid, rblock, 0, s>>>(x, gamma, beta, y, mean, rstd, N, E, eps, cb, hw);
+        DRM_LAUNCH_CHECK();
+        return DRM_OK;
+    }
     const dim3 grid((unsigned)N), block(LNS_THREADS);
     if (E <= 4096) k_lnsilu_fwd<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
     else if (E <= 8192) k_lnsilu_fwd<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
@@ -215,14 +320,18 @@ extern "C" int drm_ln_silu_backward(const float* x, const float* dy, const float
     DRM_REQUIRE(!channel_bias || (hw >= 4 && hw % 4 == 0 && E % hw == 0 && sample_sums), DRM_EINVAL,
                 "channel bias needs hw %% 4 == 0, E %% hw == 0 and the per-sample sums buffer");
     const float* cb = channel_bias;
-    if (!cb) sample_sums = nullptr;
     DRM_REQUIRE(dy && mean && rstd && dx && param_partials && aligned16(dy) && aligned16(dx) && aligned16(param_partials),
                 DRM_EINVAL, "null or misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)N), block(LNS_THREADS);
     {
         ProfScope prof(PC_ELEMENTWISE, s, 30.0 * N * E, 12.0 * N * E + 8.0 * E);
-        if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
+        const dim3 rgrid((unsigned)((N + 3) / 4)), rblock(256);
+        if (E <= 256) k_lnsilu_row_bwd_dx<1><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
+        else if (E <= 512) k_lnsilu_row_bwd_dx<2><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
+        else if (E <= 1024) k_lnsilu_row_bwd_dx<4><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
+        else if (E <= 2048) k_lnsilu_row_bwd_dx<8><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
+        else if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
         else if (E <= 8192) k_lnsilu_bwd_dx<2><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
         else if (E <= 16384) k_lnsilu_bwd_dx<4><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
         else k_lnsilu_bwd_dx<8><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);

@@ -33,12 +33,58 @@ class WorldModelState:
     z: torch.Tensor  # (B, L, K) one-hot, or (B, T, L, K)
 
 
+class _LinearNormActFn(torch.autograd.Function):
+    """nn.Linear -> nn.LayerNorm(width) -> nn.SiLU on (rows, in) inputs: the GEMMs stay torch's, the
+    normalisation + activation and their backward (with the Linear's bias gradient as a by-product of
+    the parameter-gradient pass) are the library's row kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, eps):
+        from . import _native as N
+        pre = torch.addmm(b, x, w.t())
+        y, mean, rstd = N.ln_silu_forward(pre, gamma, beta, eps)
+        ctx.save_for_backward(x, w, pre, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _native as N
+        x, w, pre, gamma, beta, mean, rstd = ctx.saved_tensors
+        dpre, dparams, db = N.ln_silu_backward(pre, dy.contiguous(), gamma, beta, mean, rstd, want_dx_sum=True)
+        dx = dpre @ w if ctx.needs_input_grad[0] else None
+        return dx, dpre.t() @ x, db, dparams[0], dparams[1], None
+
+
+class _MLP(nn.Sequential):
+    """nn.Sequential of (Linear, LayerNorm, SiLU) triples; on the GPU each triple runs as one fused block."""
+
+    fuse = os.environ.get("DRM_NO_MLP_FUSION", "0") != "1"
+
+    def forward(self, x):
+        mods = list(self)
+        if not (self.fuse and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= 1):
+            return super().forward(x)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.Linear) and m.bias is not None and i + 2 < len(mods) and isinstance(mods[i + 1], nn.LayerNorm)
+                    and isinstance(mods[i + 2], nn.SiLU) and tuple(mods[i + 1].normalized_shape) == (m.out_features,)
+                    and m.out_features % 4 == 0 and m.out_features <= 2048):
+                ln = mods[i + 1]
+                x = _LinearNormActFn.apply(x.contiguous(), m.weight, m.bias, ln.weight, ln.bias, ln.eps)
+                i += 3
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 def _norm_act_mlp(in_dim: int, width: int, depth: int) -> nn.Sequential:
     """depth x (Linear, LayerNorm, SiLU), laid out so that state-dict keys are mlp.{0,1,3,4,...}."""
     mods = []
     for i in range(depth):
         mods += [nn.Linear(in_dim if i == 0 else width, width), nn.LayerNorm(width), nn.SiLU()]
-    return nn.Sequential(*mods)
+    return _MLP(*mods)
 
 
 def hard_sample(log_probs: torch.Tensor, expo: Optional[torch.Tensor] = None):

@@ -337,7 +337,9 @@ int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io,
  * produced x (nn.Conv2d / nn.ConvTranspose2d bias of the same stage) is added on the way in, i.e. the
  * block computes SiLU(LayerNorm(x + b[c])) and the convolution runs without its bias pass.  Backward then
  * needs sample_sums (2N floats, scratch) and writes param_partials (slices, 3, E); the third row summed
- * over slices and over the hw positions of a channel is d b[c]. */
+ * over slices and over the hw positions of a channel is d b[c].  sample_sums without a channel bias
+ * also selects the three-row form: the third row summed over slices is sum_n dx[n, e], the bias
+ * gradient of a Linear in front of nn.LayerNorm(E) + nn.SiLU (the MLP blocks of lib/world_model.py:153-160). */
 int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, drm_stream_t stream);
 int32_t drm_ln_silu_slices(int64_t N, int32_t E);

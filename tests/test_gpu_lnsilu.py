@@ -62,3 +62,24 @@ def test_tower_with_folded_conv_bias_matches_plain_sequential(monkeypatch):
     assert rel(out, ref) < 1e-5
     for (name, _), a, r in zip(enc.conv.named_parameters(), g_out, g_ref):
         assert rel(a, r) < 2e-4, name
+
+
+@pytest.mark.parametrize("rows,k,width", [(1024, 1536, 512), (240, 512, 512), (7, 96, 64), (1, 32, 2048), (50, 64, 100)])
+def test_fused_mlp_block_matches_linear_layer_norm_silu(rows, k, width):
+    """Linear -> LayerNorm -> SiLU block (lib/world_model.py:153-160) with the library's row kernels: values and all gradients."""
+    from dreamer_amd.world_model import _LinearNormActFn
+    g = torch.Generator().manual_seed(rows + width)
+    x = torch.randn(rows, k, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(width, k, generator=g) / k ** 0.5).to(DEV).requires_grad_(True)
+    b = (0.3 * torch.randn(width, generator=g)).to(DEV).requires_grad_(True)
+    ga = (1.0 + 0.2 * torch.randn(width, generator=g)).to(DEV).requires_grad_(True)
+    be = (0.1 * torch.randn(width, generator=g)).to(DEV).requires_grad_(True)
+    dy = torch.randn(rows, width, generator=g).to(DEV)
+    ref = F.silu(F.layer_norm(F.linear(x, w, b), (width,), ga, be, 1e-5))
+    g_ref = torch.autograd.grad(ref, (x, w, b, ga, be), dy)
+    out = _LinearNormActFn.apply(x, w, b, ga, be, 1e-5)
+    g_out = torch.autograd.grad(out, (x, w, b, ga, be), dy)
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / (r.double().abs().max() + 1e-30))
+    assert rel(out, ref) < 5e-6
+    for name, a, r in zip("x w b gamma beta".split(), g_out, g_ref):
+        assert rel(a, r) < 3e-5, name
