@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--train-steps", type=int, default=20, help="full training updates to time as well (0 = skip)")
-    ap.add_argument("--train-limit-s", type=float, default=240.0, help="give up on the training updates after this long")
+    ap.add_argument("--train-limit-s", type=float, default=420.0, help="give up on the training updates after this long")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
