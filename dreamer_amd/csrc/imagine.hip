@@ -6,6 +6,7 @@
 #include "linear_big.hpp"
 
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -655,6 +656,12 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
     BigLaunch L{};
     int tiles = 0;
     double fl = 0, by = 0;
+    // 64-column tiles when 128-column ones would give fewer than two workgroups per CU (fp32 form)
+    int tiles128 = 0;
+    for (int i = 0; i < np; ++i) tiles128 += (specs[i].N + BIG_BN - 1) / BIG_BN;
+    const bool narrow = precision != 1 && (int64_t)tiles128 * ((M + BIG_BM - 1) / BIG_BM) < 512 &&
+                        std::getenv("DRM_NO_NARROW_TILES") == nullptr;
+    const int bn = narrow ? BIG_BN64 : BIG_BN;
     for (int i = 0; i < np; ++i) {
         const ProblemSpec& q = specs[i];
         DRM_REQUIRE(q.X && q.W && q.Y && q.K >= 32 && q.K % 32 == 0 && q.N >= 1, DRM_EINVAL, "bad big problem");
@@ -664,15 +671,17 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
         BigProblem& p = L.p[i];
         p.X = q.X; p.ldx = q.ldx; p.W = q.W; p.ldw = q.ldw; p.bias = q.bias; p.tab = q.tab; p.ldt = q.ldt;
         p.Y = q.Y; p.ldy = q.ldy; p.N = q.N; p.K = q.K; p.tile_begin = tiles;
-        tiles += (q.N + BIG_BN - 1) / BIG_BN;
+        tiles += (q.N + bn - 1) / bn;
         const double n = q.N, k = q.K, m = M;
         fl += 2.0 * m * n * k + (q.tab ? (double)latents * m * n : 0.0);
         by += 4.0 * (m * k + n * k + n + m * n) + (q.tab ? 4.0 * latents * classes * n + (double)latents * m : 0.0);
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
-    if (precision == 1) k_linear_big_bf16<<<dim3(tiles, (M + BIG_BM - 1) / BIG_BM), dim3(256), 0, stream>>>(L);
-    else k_linear_big<<<dim3(tiles, (M + BIG_BM - 1) / BIG_BM), dim3(256), 0, stream>>>(L);
+    const dim3 grid(tiles, (M + BIG_BM - 1) / BIG_BM);
+    if (precision == 1) k_linear_big_bf16<<<grid, dim3(256), 0, stream>>>(L);
+    else if (narrow) k_linear_big64<<<grid, dim3(256), 0, stream>>>(L);
+    else k_linear_big<<<grid, dim3(256), 0, stream>>>(L);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

@@ -206,6 +206,154 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
     }
 }
 
+// ---- 64 x 64 tiles: the same kernel for launches whose 64 x 128 grid would leave one workgroup per CU --
+// (e.g. 4096 rows x 512 columns = 256 tiles).  Twice the workgroups, two resident per CU, so one
+// workgroup's prologue (first operand fetch) and epilogue overlap the other's K loop.  Waves 2 x 2, one
+// 32 x 32 accumulator each.
+constexpr int BIG_BN64 = 64;
+#define BIG64_FRAG(buf, g, A, B0)                                                                     \
+    A = *reinterpret_cast<const float4*>(&sA[buf][wm * 32 + li][(g) * 8 + lh * 4]);                  \
+    B0 = *reinterpret_cast<const float4*>(&sB[buf][wn * 32 + li][(g) * 8 + lh * 4]);
+#define BIG64_MMA4(A, B0)                                                                             \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B0.x, acc0, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B0.y, acc0, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B0.z, acc0, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B0.w, acc0, 0, 0, 0);
+#define BIG64_STEP(buf)                                                                               \
+    {                                                                                                 \
+        float4 fa0, fb0, fa1, fb1;                                                                    \
+        BIG64_FRAG(buf, 0, fa0, fb0)                                                                  \
+        BIG64_FRAG(buf, 1, fa1, fb1)                                                                  \
+        BIG64_MMA4(fa0, fb0)                                                                          \
+        BIG64_FRAG(buf, 2, fa0, fb0)                                                                  \
+        BIG64_MMA4(fa1, fb1)                                                                          \
+        BIG64_FRAG(buf, 3, fa1, fb1)                                                                  \
+        BIG64_MMA4(fa0, fb0)                                                                          \
+        BIG64_MMA4(fa1, fb1)                                                                          \
+    }
+
+__global__ __launch_bounds__(256) void k_linear_big64(const BigLaunch L) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BIG_BM + BIG_BN64) * BIG_LD];
+    float (*sA)[BIG_BM][BIG_LD] = reinterpret_cast<float (*)[BIG_BM][BIG_LD]>(smem);
+    float (*sB)[BIG_BN64][BIG_LD] = reinterpret_cast<float (*)[BIG_BN64][BIG_LD]>(smem + 2 * BIG_BM * BIG_LD);
+
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    int lin = blockIdx.y * nbx + blockIdx.x;
+    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+    const int bx = lin % nbx, by = lin / nbx;
+
+    int pi = L.np - 1;
+    while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
+    const BigProblem& P = L.p[pi];
+    const int n0 = (bx - P.tile_begin) * BIG_BN64;
+    const int m0 = by * BIG_BM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = P.K;
+
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    const float* xa[2];
+    const float* wb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
+        wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+    }
+    const int nk = K / BIG_BK;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a00, a01, b00, b01;   // stage 0 (even K-steps)
+    float4 a10, a11, b10, b11;   // stage 1 (odd K-steps)
+#define BIG64_LOAD(S, ko)                                                   \
+    a##S##0 = *reinterpret_cast<const float4*>(xa[0] + (ko));               \
+    a##S##1 = *reinterpret_cast<const float4*>(xa[1] + (ko));               \
+    b##S##0 = *reinterpret_cast<const float4*>(wb[0] + (ko));               \
+    b##S##1 = *reinterpret_cast<const float4*>(wb[1] + (ko));
+#define BIG64_STORE(S, buf)                                                 \
+    *reinterpret_cast<float4*>(&sA[buf][srow][skq]) = a##S##0;              \
+    *reinterpret_cast<float4*>(&sA[buf][srow + 32][skq]) = a##S##1;         \
+    *reinterpret_cast<float4*>(&sB[buf][srow][skq]) = b##S##0;              \
+    *reinterpret_cast<float4*>(&sB[buf][srow + 32][skq]) = b##S##1;
+    BIG64_LOAD(0, 0)
+    a10 = a11 = b10 = b11 = zero4;
+    if (nk > 1) { BIG64_LOAD(1, BIG_BK) }
+
+    f32x16 acc0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = 0.f;
+
+    for (int ks = 0; ks < nk; ks += 2) {
+        BIG64_STORE(0, 0)
+        __syncthreads();
+        if (ks + 2 < nk) { BIG64_LOAD(0, (ks + 2) * BIG_BK) }
+        BIG64_STEP(0)
+        if (ks + 1 < nk) {
+            BIG64_STORE(1, 1)
+            __syncthreads();
+            if (ks + 3 < nk) { BIG64_LOAD(1, (ks + 3) * BIG_BK) }
+            BIG64_STEP(1)
+        }
+    }
+#undef BIG64_LOAD
+#undef BIG64_STORE
+
+    __syncthreads();
+    float (*sC)[BIG_BN64 + 4] = reinterpret_cast<float (*)[BIG_BN64 + 4]>(smem);   // 64 x 68 words
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 + li] = acc0[i];
+    __syncthreads();
+    const int c4 = (tid & 15) * 4;            // 16 threads cover the 64 columns of a row
+    const int n = n0 + c4;
+    if (n >= P.N) return;
+    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) {
+        bias.x = P.bias[n];
+        if (n + 1 < P.N) bias.y = P.bias[n + 1];
+        if (n + 2 < P.N) bias.z = P.bias[n + 2];
+        if (n + 3 < P.N) bias.w = P.bias[n + 3];
+    }
+    for (int r = tid >> 4; r < BIG_BM; r += 16) {
+        const int m = m0 + r;
+        if (m >= L.M) break;
+        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
+        if (P.tab != nullptr) {
+            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
+            if (vec) {
+                for (int l = 0; l < L.latents; l += 8) {
+                    float4 u[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ll = min(l + j, L.latents - 1);
+                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
+                }
+            } else {
+                for (int l = 0; l < L.latents; ++l) {
+                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
+                    y.x += tb[0];
+                    if (n + 1 < P.N) y.y += tb[1];
+                    if (n + 2 < P.N) y.z += tb[2];
+                    if (n + 3 < P.N) y.w += tb[3];
+                }
+            }
+        }
+        float* out = P.Y + (int64_t)m * P.ldy + n;
+        if (vec) {
+            *reinterpret_cast<float4*>(out) = y;
+        } else {
+            out[0] = y.x;
+            if (n + 1 < P.N) out[1] = y.y;
+            if (n + 2 < P.N) out[2] = y.z;
+            if (n + 3 < P.N) out[3] = y.w;
+        }
+    }
+}
+
 // ---- bf16 matrix inputs, fp32 accumulation (v_mfma_f32_32x32x16_bf16) ------------------------------
 // Same tiling and epilogue as k_linear_big.  Operands stay fp32 in memory and are rounded to bf16
 // (round to nearest even) on their way into LDS; a lane's fragment is 8 consecutive k = one 16-byte LDS
