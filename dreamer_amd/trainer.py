@@ -17,6 +17,8 @@ only rank 0 logs and writes checkpoints.
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import os
 import time
 from typing import Dict, Optional
@@ -39,6 +41,22 @@ from .world_model import WorldModel, WorldModelState
 def _adam(params, lr, eps, capturable=False):
     params = list(params)
     return torch.optim.Adam(params, lr=lr, eps=eps, fused=params[0].is_cuda, capturable=capturable and params[0].is_cuda)
+
+
+@contextlib.contextmanager
+def _recording(graph):
+    """torch.cuda.graph(graph) with the cyclic garbage collector held off: a collection that runs while
+    the stream is recording may free pinned memory, streams or other graphs, calls the runtime refuses
+    during a recording (the process then aborts in a destructor)."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _clip_and_step(optim, params, clip: float) -> None:
@@ -92,7 +110,7 @@ class _GraphedUpdate:
         torch.cuda.synchronize()
         torch.cuda.set_rng_state(rng)   # the rehearsal drew noise; the recorded update must continue the eager sequence
         self.g_loss = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_loss):
+        with _recording(self.g_loss):
             self.grads.zero()
             self.loss_out = self.loss_fn(*self.static)
             self.loss_out.backward()
@@ -100,7 +118,7 @@ class _GraphedUpdate:
 
     def _capture_step(self, params) -> None:
         self.g_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_step):
+        with _recording(self.g_step):
             _clip_and_step(self.optim, params, self.clip)
             if self.post is not None:
                 self.post()
@@ -177,7 +195,7 @@ class ActingPolicy:
             if self.graph is None:   # recording launches nothing: the step itself is the replay below
                 torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                with _recording(self.graph):
                     self._step()
             self.graph.replay()
         else:

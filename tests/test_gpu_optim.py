@@ -60,7 +60,8 @@ def test_flat_adam_in_a_recorded_graph():
     graph = torch.cuda.CUDAGraph()
     grads.flat.normal_()
     torch.cuda.synchronize()
-    with torch.cuda.graph(graph):
+    from dreamer_amd.trainer import _recording
+    with _recording(graph):
         opt.step()
     for i in range(4):
         gr = torch.randn_like(grads.flat)
