@@ -71,3 +71,32 @@ def test_flat_adam_in_a_recorded_graph():
         opt_ref.step()
     assert float(opt.step_count) == float(opt_ref.step_count) == 4.0
     assert torch.equal(grads.flat_params, opt_ref.grads.flat_params)
+
+
+def test_state_dict_round_trips_through_torch_adam():
+    """A checkpoint written from the flat optimiser loads into torch.optim.Adam (the reference's optimiser,
+    lib/trainer.py:95-103, saved at :326-335) and into a fresh flat optimiser; both continue identically."""
+    a, b, c = _model(3), _model(3), _model(3)
+    ga = FlatGrads(a, static=True)
+    oa = FlatAdam(ga, lr=1e-3, eps=1e-8, clip=0.0)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for _ in range(3):
+        ga.flat.copy_(torch.randn(ga.flat.numel(), device=DEV, generator=g))
+        oa.step()
+    sd = oa.state_dict()
+    with torch.no_grad():
+        for pa, pb, pc in zip(a.parameters(), b.parameters(), c.parameters()):
+            pb.copy_(pa); pc.copy_(pa)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3, eps=1e-8, fused=True)
+    ob.load_state_dict(sd)
+    gc_ = FlatGrads(c, static=True)
+    oc = FlatAdam(gc_, lr=1e-3, eps=1e-8, clip=0.0)
+    oc.load_state_dict(sd)
+    grad = torch.randn(ga.flat.numel(), device=DEV, generator=g)
+    ga.flat.copy_(grad); gc_.flat.copy_(grad)
+    for pb, view in zip(b.parameters(), ga.views):
+        pb.grad = view.clone()
+    oa.step(); ob.step(); oc.step()
+    for pa, pb, pc in zip(a.parameters(), b.parameters(), c.parameters()):
+        assert torch.equal(pa, pc)
+        assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1e-3)
