@@ -112,6 +112,7 @@ SIGNATURES = {
                              + [C.c_void_p] * 5),
     "drm_mse_rows_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_mse_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "drm_convt_k4s2_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_adam_workspace_bytes": (C.c_size_t, []),
     "drm_adam_flat_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 5 + [C.c_void_p] * 4),
     "drm_copy_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -267,6 +268,18 @@ def onehot_to_index(z: torch.Tensor) -> torch.Tensor:
     check(lib().drm_onehot_to_index(z.data_ptr(), z.numel() // K, K, idx.data_ptr(), stream_ptr(z.device)),
           "drm_onehot_to_index")
     return idx
+
+
+def convt_k4s2_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """ConvTranspose2d(kernel 4, stride 2, padding 1) + bias for at most 4 output channels."""
+    require_cuda(x, weight)
+    _dense(x, torch.float32, "x"); _dense(weight, torch.float32, "weight")
+    n, cin, h, w = x.shape
+    cout = weight.shape[1]
+    y = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    check(lib().drm_convt_k4s2_forward(x.data_ptr(), weight.data_ptr(), ptr(bias), y.data_ptr(), n, cin, cout, h, w,
+                                       stream_ptr(x.device)), "drm_convt_k4s2_forward")
+    return y
 
 
 def copy_pair(a_dst: torch.Tensor, a_src: torch.Tensor, b_dst: torch.Tensor, b_src: torch.Tensor) -> None:

@@ -131,10 +131,17 @@ class _ConvBiasFn(torch.autograd.Function):
     gradient on MI355X against 33 us for the two-step form, twice per world-model update.  Input and
     weight gradients come from the same backend routine autograd would call."""
 
+    native_convt = os.environ.get("DRM_NO_NATIVE_CONVT", "0") != "1"
+
     @staticmethod
     def forward(ctx, x, weight, bias, transposed, stride, padding):
         ctx.save_for_backward(x, weight)
         ctx.conf = (transposed, stride, padding)
+        if (transposed and weight.shape[1] <= 4 and tuple(weight.shape[2:]) == (4, 4) and tuple(stride) == (2, 2)
+                and tuple(padding) == (1, 1) and x.dtype == torch.float32 and _ConvBiasFn.native_convt):
+            # few output channels: a stream, served by the library's direct kernel (bias included)
+            from . import _native as N
+            return N.convt_k4s2_forward(x.contiguous(), weight.contiguous(), bias)
         if transposed:
             return F.conv_transpose2d(x, weight, bias, stride=stride, padding=padding)
         return F.conv2d(x, weight, bias, stride=stride, padding=padding)

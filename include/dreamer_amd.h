@@ -113,6 +113,12 @@ int drm_mse_rows_forward(const float* x_hat, const float* x, int64_t rows, int32
 int drm_mse_rows_backward(const float* x_hat, const float* x, int64_t rows, int32_t E, const float* g, float* d_x_hat,
                           drm_stream_t stream);
 
+/* nn.ConvTranspose2d(Cin, Cout <= 4, kernel 4, stride 2, padding 1) + bias, forward: the last decoder stage
+ * (lib/world_model.py:298-302).  x (N, Cin, H, W), weight (Cin, Cout, 4, 4) (torch's layout), bias (Cout) or
+ * NULL, y (N, Cout, 2H, 2W); all contiguous fp32. */
+int drm_convt_k4s2_forward(const float* x, const float* weight, const float* bias, float* y, int64_t N, int32_t Cin,
+                           int32_t Cout, int32_t H, int32_t W, drm_stream_t stream);
+
 /* Optimiser step on flat buffers: global-norm clip (torch.nn.utils.clip_grad_norm_, coefficient
  * min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clip) followed by Adam without weight decay, the
  * arithmetic of torch's fused Adam (lib/trainer.py:95-103 creates the optimisers, :170-173, :231-235,
