@@ -99,9 +99,11 @@ SIGNATURES = {
     "drm_prof_summary": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
     "drm_lambda_return": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
-    "drm_ln_silu_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
+    "drm_ln_silu_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_void_p]),
     "drm_ln_silu_slices": (C.c_int32, [C.c_int64, C.c_int32]),
-    "drm_ln_silu_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "drm_ln_silu_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p]),
     "drm_seq_gather": (C.c_int, [C.POINTER(drm_ring), C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
     "drm_sample_categorical_st": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -204,12 +206,29 @@ def seq_gather(obs, actions, rewards, continues, starts, T: int, want_f32: bool 
     return o, a, r, c, f
 
 
+def _is_channels_last(x: torch.Tensor) -> bool:
+    return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def _dense_or_cl(x: torch.Tensor, name: str) -> bool:
+    """True for a channels-last (N, C, H, W) tensor, False for a plain contiguous one; anything else is rejected."""
+    if _is_channels_last(x):
+        if x.dtype != torch.float32:
+            raise ValueError(f"{name} must be float32")
+        return True
+    _dense(x, torch.float32, name)
+    return False
+
+
 def ln_silu_forward(x, gamma, beta, eps: float, channel_bias=None):
-    """y = SiLU(LayerNorm over each whole sample of x (+ channel_bias[c]), x viewed as (N, E)); returns y, mean (N), rstd (N)."""
+    """y = SiLU(LayerNorm over each whole sample of x (+ channel_bias[c])); returns y (x's memory format), mean (N), rstd (N)."""
     require_cuda(x, gamma, beta)
-    _dense(x, torch.float32, "x"); _dense(gamma, torch.float32, "gamma"); _dense(beta, torch.float32, "beta")
+    cl = _dense_or_cl(x, "x")
+    _dense(gamma, torch.float32, "gamma"); _dense(beta, torch.float32, "beta")
     N, E = x.shape[0], gamma.numel()
     hw = 0
+    if cl:
+        hw = x.shape[2] * x.shape[3]
     if channel_bias is not None:
         _dense(channel_bias, torch.float32, "channel_bias")
         hw = E // channel_bias.numel()
@@ -217,32 +236,34 @@ def ln_silu_forward(x, gamma, beta, eps: float, channel_bias=None):
     mean = torch.empty(N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N, dtype=torch.float32, device=x.device)
     check(lib().drm_ln_silu_forward(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                    rstd.data_ptr(), N, E, float(eps), ptr(channel_bias), hw, stream_ptr(x.device)),
+                                    rstd.data_ptr(), N, E, float(eps), ptr(channel_bias), hw, int(cl), stream_ptr(x.device)),
           "drm_ln_silu_forward")
     return y, mean, rstd
 
 
 def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None, want_dx_sum=False):
     """dx and [d gamma; d beta] (2, E) of ln_silu_forward; with a channel bias a third result, d bias (C);
-    with ``want_dx_sum`` a third result sum_n dx[n] (E)."""
+    with ``want_dx_sum`` a third result sum_n dx[n] (E).  ``dy`` must have x's memory format."""
     require_cuda(x, dy, gamma, beta, mean, rstd)
-    _dense(x, torch.float32, "x"); _dense(dy, torch.float32, "dy")
+    cl = _dense_or_cl(x, "x")
+    if _dense_or_cl(dy, "dy") != cl:
+        raise ValueError("dy must have the memory format of x")
     N, E = x.shape[0], gamma.numel()
     slices = lib().drm_ln_silu_slices(N, E)
     dx = torch.empty_like(x)
     rows = 2 if (channel_bias is None and not want_dx_sum) else 3
     part = torch.empty((slices, rows, E), dtype=torch.float32, device=x.device)
     sums = None if rows == 2 else torch.empty(2 * N, dtype=torch.float32, device=x.device)
-    hw = 0 if channel_bias is None else E // channel_bias.numel()
+    hw = x.shape[2] * x.shape[3] if cl else (0 if channel_bias is None else E // channel_bias.numel())
     check(lib().drm_ln_silu_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                                     rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, ptr(channel_bias), hw, ptr(sums),
-                                     stream_ptr(x.device)), "drm_ln_silu_backward")
+                                     rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, ptr(channel_bias), hw, int(cl),
+                                     ptr(sums), stream_ptr(x.device)), "drm_ln_silu_backward")
     total = part.sum(0)
     if rows == 2:
         return dx, total
     if channel_bias is None:
         return dx, total[:2], total[2]
-    return dx, total[:2], total[2].view(channel_bias.numel(), hw).sum(1)
+    return dx, total[:2], total[2].view(channel_bias.numel(), E // channel_bias.numel()).sum(1)
 
 
 def sample_categorical_st(logits, expo, unimix_eps: Optional[float], want_z=True, want_idx=True, want_y=False):

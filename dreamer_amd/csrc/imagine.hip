@@ -494,6 +494,7 @@ struct SampleRowsArgs {
     float* logits_out; int64_t ldlo;
     int B, L;
     float log1m_eps, log_eps_over_k;
+    float one_m_eps, eps_over_k;             // 1 - unimix_eps, unimix_eps / K
 };
 
 __global__ __launch_bounds__(256) void k_sample_rows(const SampleRowsArgs P) {
@@ -503,27 +504,20 @@ __global__ __launch_bounds__(256) void k_sample_rows(const SampleRowsArgs P) {
         const int b = (int)(it / P.L), l = (int)(it - (int64_t)b * P.L);
         const float4 lg = *reinterpret_cast<const float4*>(P.logits + (int64_t)b * P.ldlg + l * 32 + sub * 4);
         const float4 ex = *reinterpret_cast<const float4*>(P.expo + (int64_t)b * P.lde + l * 32 + sub * 4);
-        float v[4] = {lg.x, lg.y, lg.z, lg.w};
+        // argmax_k softmax(log_unimix(logits) - log E)_k = argmax_k ((1-eps) softmax(logits)_k + eps/K) / E_k
+        const float v[4] = {lg.x, lg.y, lg.z, lg.w};
         const float e[4] = {ex.x, ex.y, ex.z, ex.w};
         const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-        float s = 0.f;
+        float pj[4], s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += expf(v[j] - mx);
-        const float lse = logf(group_sum<8>(s));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = logaddexp_f((v[j] - mx - lse) + P.log1m_eps, P.log_eps_over_k) - logf(e[j]);
-        const float smax = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-        float y[4];
-        s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { y[j] = expf(v[j] - smax); s += y[j]; }
-        s = group_sum<8>(s);
+        for (int j = 0; j < 4; ++j) { pj[j] = expf(v[j] - mx); s += pj[j]; }
+        const float scale = P.one_m_eps / group_sum<8>(s);
         float best = -1.f;
         int bi = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j] = y[j] / s;
-            if (y[j] > best) { best = y[j]; bi = sub * 4 + j; }
+            const float q = fmaf(pj[j], scale, P.eps_over_k) / e[j];
+            if (q > best) { best = q; bi = sub * 4 + j; }
         }
         group_argmax<8>(best, bi);
         int used = bi;
@@ -1070,8 +1064,9 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             a.z_dense = io->z_out ? io->z_out + (size_t)t * LK : nullptr; a.ldzd = (int64_t)H * LK;
             a.logits_out = io->prior_logits_out ? io->prior_logits_out + (size_t)t * LK : nullptr; a.ldlo = (int64_t)H * LK;
             a.B = B; a.L = L; a.log1m_eps = l1m; a.log_eps_over_k = lek;
+            a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
             const int64_t blocks = ((int64_t)B * L + 31) / 32;
-            ProfScope prof(PC_SAMPLE, s, 40.0 * B * LK, (double)B * L * (256.0 + (a.z_dense ? 128.0 : 0.0) + 1.0));
+            ProfScope prof(PC_SAMPLE, s, 12.0 * B * LK, (double)B * L * (256.0 + (a.z_dense ? 128.0 : 0.0) + 1.0));
             k_sample_rows<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s>>>(a);
             DRM_LAUNCH_CHECK();
         } else {

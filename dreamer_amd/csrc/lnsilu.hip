@@ -33,11 +33,34 @@ __device__ __forceinline__ float block_sum_1024(float v, float* s16) {
     return t;
 }
 
+// Channels-last samples: the data of a sample is laid out (position, channel) while gamma / beta (and the
+// parameter-gradient rows) keep the module's (channel, position) order.  clC = number of channels (0: the
+// data is in parameter order), hw = positions per channel.  Four consecutive data elements are four
+// consecutive channels of one position.
+__device__ __forceinline__ float4 lns_param4(const float* __restrict__ p, int e, int clC, int hw) {
+    if (clC == 0) return *reinterpret_cast<const float4*>(p + e);
+    const int c = e % clC, pos = e / clC;
+    const float* q = p + (int64_t)c * hw + pos;
+    return make_float4(q[0], q[hw], q[2 * hw], q[3 * hw]);
+}
+__device__ __forceinline__ void lns_store_param4(float* __restrict__ p, int e, int clC, int hw, float4 v) {
+    if (clC == 0) { *reinterpret_cast<float4*>(p + e) = v; return; }
+    const int c = e % clC, pos = e / clC;
+    float* q = p + (int64_t)c * hw + pos;
+    q[0] = v.x; q[hw] = v.y; q[2 * hw] = v.z; q[3 * hw] = v.w;
+}
+__device__ __forceinline__ float4 lns_cbias4(const float* __restrict__ cbias, int e, int clC, int hw) {
+    if (cbias == nullptr) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (clC != 0) return *reinterpret_cast<const float4*>(cbias + e % clC);
+    const float b = cbias[e / hw];
+    return make_float4(b, b, b, b);
+}
+
 template <int NV>
 __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_fwd(const float* __restrict__ X, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ Y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int E, float eps, const float* __restrict__ cbias, int hw) {
+                                                            int E, float eps, const float* __restrict__ cbias, int hw, int clC) {
     __shared__ float s16[16];
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -48,7 +71,7 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_fwd(const float* __restr
     for (int i = 0; i < NV; ++i) {
         const int e = (i * LNS_THREADS + tid) * 4;
         v[i] = e < E ? *reinterpret_cast<const float4*>(x + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cbias != nullptr && e < E) { const float b = cbias[e / hw]; v[i].x += b; v[i].y += b; v[i].z += b; v[i].w += b; }
+        if (cbias != nullptr && e < E) { const float4 b = lns_cbias4(cbias, e, clC, hw); v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w; }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = block_sum_1024(s, s16) / (float)E;
@@ -67,8 +90,8 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_fwd(const float* __restr
     for (int i = 0; i < NV; ++i) {
         const int e = (i * LNS_THREADS + tid) * 4;
         if (e < E) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + e);
-            const float4 b = *reinterpret_cast<const float4*>(beta + e);
+            const float4 g = lns_param4(gamma, e, clC, hw);
+            const float4 b = lns_param4(beta, e, clC, hw);
             float4 o;
             o.x = silu_f((v[i].x - mean) * rstd * g.x + b.x);
             o.y = silu_f((v[i].y - mean) * rstd * g.y + b.y);
@@ -89,7 +112,7 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                                float* __restrict__ dX, int E, const float* __restrict__ cbias, int hw,
-                                                               float* __restrict__ sums_out) {
+                                                               float* __restrict__ sums_out, int clC) {
     __shared__ float s16[16];
     const int64_t n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -102,9 +125,9 @@ __global__ __launch_bounds__(LNS_THREADS) void k_lnsilu_bwd_dx(const float* __re
         if (e < E) {
             float4 xv = *reinterpret_cast<const float4*>(X + n * E + e);
             const float4 dy = *reinterpret_cast<const float4*>(dY + n * E + e);
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
-            const float4 be = *reinterpret_cast<const float4*>(beta + e);
-            if (cbias != nullptr) { const float b = cbias[e / hw]; xv.x += b; xv.y += b; xv.z += b; xv.w += b; }
+            const float4 ga = lns_param4(gamma, e, clC, hw);
+            const float4 be = lns_param4(beta, e, clC, hw);
+            if (cbias != nullptr) { const float4 b = lns_cbias4(cbias, e, clC, hw); xv.x += b.x; xv.y += b.y; xv.z += b.z; xv.w += b.w; }
             xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd; xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
             g[i].x = dsilu_times(dy.x, xh[i].x * ga.x + be.x) * ga.x;
             g[i].y = dsilu_times(dy.y, xh[i].y * ga.y + be.y) * ga.y;
@@ -235,20 +258,21 @@ __global__ __launch_bounds__(256) void k_lnsilu_bwd_params(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                            float* __restrict__ part, int N, int E, int per_slice,
-                                                           const float* __restrict__ cbias, int hw, const float* __restrict__ sums) {
+                                                           const float* __restrict__ cbias, int hw, const float* __restrict__ sums,
+                                                           int clC) {
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= E) return;
-    const float cb = cbias != nullptr ? cbias[e / hw] : 0.f;
+    const float4 cb = lns_cbias4(cbias, e, clC, hw);
     float4 dxs = make_float4(0.f, 0.f, 0.f, 0.f);
     const int n0 = blockIdx.y * per_slice, n1 = min(n0 + per_slice, N);
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + e);
-    const float4 be = *reinterpret_cast<const float4*>(beta + e);
+    const float4 ga = lns_param4(gamma, e, clC, hw);
+    const float4 be = lns_param4(beta, e, clC, hw);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
     for (int n = n0; n < n1; ++n) {
         const float mean = mean_in[n], rstd = rstd_in[n];
         float4 xv = *reinterpret_cast<const float4*>(X + (int64_t)n * E + e);
         const float4 dy = *reinterpret_cast<const float4*>(dY + (int64_t)n * E + e);
-        xv.x += cb; xv.y += cb; xv.z += cb; xv.w += cb;
+        xv.x += cb.x; xv.y += cb.y; xv.z += cb.z; xv.w += cb.w;
         const float x0 = (xv.x - mean) * rstd, x1 = (xv.y - mean) * rstd, x2 = (xv.z - mean) * rstd, x3 = (xv.w - mean) * rstd;
         const float d0 = dsilu_times(dy.x, x0 * ga.x + be.x), d1 = dsilu_times(dy.y, x1 * ga.y + be.y);
         const float d2 = dsilu_times(dy.z, x2 * ga.z + be.z), d3 = dsilu_times(dy.w, x3 * ga.w + be.w);
@@ -262,9 +286,9 @@ __global__ __launch_bounds__(256) void k_lnsilu_bwd_params(const float* __restri
     }
     const int rows = sums != nullptr ? 3 : 2;
     float* row = part + (int64_t)blockIdx.y * rows * E;
-    *reinterpret_cast<float4*>(row + e) = dg;
-    *reinterpret_cast<float4*>(row + E + e) = db;
-    if (sums != nullptr) *reinterpret_cast<float4*>(row + 2 * E + e) = dxs;
+    lns_store_param4(row, e, clC, hw, dg);          // parameter order in every row
+    lns_store_param4(row + E, e, clC, hw, db);
+    if (sums != nullptr) lns_store_param4(row + 2 * E, e, clC, hw, dxs);
 }
 
 static int lns_check(int64_t N, int E, const void* a, const void* b, const void* c) {
@@ -279,14 +303,19 @@ static int lns_check(int64_t N, int E, const void* a, const void* b, const void*
 using namespace drm;
 
 extern "C" int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                                   int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, drm_stream_t stream) {
+                                   int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, int32_t channels_last,
+                                   drm_stream_t stream) {
     if (int rc = lns_check(N, E, x, gamma, beta)) return rc;
     DRM_REQUIRE(y && mean && rstd && aligned16(y), DRM_EINVAL, "null or misaligned output");
-    DRM_REQUIRE(!channel_bias || (hw >= 4 && hw % 4 == 0 && E % hw == 0), DRM_EINVAL, "channel bias needs hw %% 4 == 0 and E %% hw == 0");
+    DRM_REQUIRE(!channel_bias || channels_last || (hw >= 4 && hw % 4 == 0 && E % hw == 0), DRM_EINVAL,
+                "channel bias needs hw %% 4 == 0 and E %% hw == 0");
+    DRM_REQUIRE(!channels_last || (hw >= 1 && E % hw == 0 && (E / hw) % 4 == 0 && (!channel_bias || aligned16(channel_bias))),
+                DRM_EINVAL, "channels-last samples need hw | E and a channel count that is a multiple of 4");
     const float* cb = channel_bias;
+    const int clC = channels_last ? E / hw : 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PC_ELEMENTWISE, s, 14.0 * N * E, 8.0 * N * E + 8.0 * E);
-    if (E <= 2048) {   // short samples: one wave each
+    if (E <= 2048 && clC == 0) {   // short samples: one wave each
         const dim3 rgrid((unsigned)((N + 3) / 4)), rblock(256);
         if (E <= 256) k_lnsilu_row_fwd<1><<<rgrid, rblock, 0, s>>>(x, gamma, beta, y, mean, rstd, N, E, eps, cb, hw);
         else if (E <= 512) k_lnsilu_row_fwd<2><<<rgrid, rblock, 0, s>>>(x, gamma, beta, y, mean, rstd, N, E, eps, cb, hw);
@@ -296,10 +325,10 @@ extern "C" int drm_ln_silu_forward(const float* x, const float* gamma, const flo
         return DRM_OK;
     }
     const dim3 grid((unsigned)N), block(LNS_THREADS);
-    if (E <= 4096) k_lnsilu_fwd<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
-    else if (E <= 8192) k_lnsilu_fwd<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
-    else if (E <= 16384) k_lnsilu_fwd<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
-    else k_lnsilu_fwd<8><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw);
+    if (E <= 4096) k_lnsilu_fwd<1><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw, clC);
+    else if (E <= 8192) k_lnsilu_fwd<2><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw, clC);
+    else if (E <= 16384) k_lnsilu_fwd<4><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw, clC);
+    else k_lnsilu_fwd<8><<<grid, block, 0, s>>>(x, gamma, beta, y, mean, rstd, E, eps, cb, hw, clC);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -315,11 +344,15 @@ extern "C" int32_t drm_ln_silu_slices(int64_t N, int32_t E) {
 
 extern "C" int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                                     const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E,
-                                    const float* channel_bias, int32_t hw, float* sample_sums, drm_stream_t stream) {
+                                    const float* channel_bias, int32_t hw, int32_t channels_last, float* sample_sums,
+                                    drm_stream_t stream) {
     if (int rc = lns_check(N, E, x, gamma, beta)) return rc;
-    DRM_REQUIRE(!channel_bias || (hw >= 4 && hw % 4 == 0 && E % hw == 0 && sample_sums), DRM_EINVAL,
+    DRM_REQUIRE(!channel_bias || (sample_sums && (channels_last || (hw >= 4 && hw % 4 == 0 && E % hw == 0))), DRM_EINVAL,
                 "channel bias needs hw %% 4 == 0, E %% hw == 0 and the per-sample sums buffer");
+    DRM_REQUIRE(!channels_last || (hw >= 1 && E % hw == 0 && (E / hw) % 4 == 0 && (!channel_bias || aligned16(channel_bias))),
+                DRM_EINVAL, "channels-last samples need hw | E and a channel count that is a multiple of 4");
     const float* cb = channel_bias;
+    const int clC = channels_last ? E / hw : 0;
     DRM_REQUIRE(dy && mean && rstd && dx && param_partials && aligned16(dy) && aligned16(dx) && aligned16(param_partials),
                 DRM_EINVAL, "null or misaligned pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -327,21 +360,22 @@ extern "C" int drm_ln_silu_backward(const float* x, const float* dy, const float
     {
         ProfScope prof(PC_ELEMENTWISE, s, 30.0 * N * E, 12.0 * N * E + 8.0 * E);
         const dim3 rgrid((unsigned)((N + 3) / 4)), rblock(256);
-        if (E <= 256) k_lnsilu_row_bwd_dx<1><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
+        if (clC != 0 && E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums, clC);
+        else if (E <= 256) k_lnsilu_row_bwd_dx<1><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
         else if (E <= 512) k_lnsilu_row_bwd_dx<2><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
         else if (E <= 1024) k_lnsilu_row_bwd_dx<4><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
         else if (E <= 2048) k_lnsilu_row_bwd_dx<8><<<rgrid, rblock, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, N, E, cb, hw, sample_sums);
-        else if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
-        else if (E <= 8192) k_lnsilu_bwd_dx<2><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
-        else if (E <= 16384) k_lnsilu_bwd_dx<4><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
-        else k_lnsilu_bwd_dx<8><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums);
+        else if (E <= 4096) k_lnsilu_bwd_dx<1><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums, clC);
+        else if (E <= 8192) k_lnsilu_bwd_dx<2><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums, clC);
+        else if (E <= 16384) k_lnsilu_bwd_dx<4><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums, clC);
+        else k_lnsilu_bwd_dx<8><<<grid, block, 0, s>>>(x, dy, gamma, beta, mean, rstd, dx, E, cb, hw, sample_sums, clC);
         DRM_LAUNCH_CHECK();
     }
     const int slices = drm_ln_silu_slices(N, E);
     const int per_slice = (int)((N + slices - 1) / slices);
     ProfScope prof(PC_ELEMENTWISE, s, 24.0 * N * E, 8.0 * N * E + 8.0 * slices * E);
     k_lnsilu_bwd_params<<<dim3((E / 4 + 255) / 256, slices), dim3(256), 0, s>>>(x, dy, gamma, beta, mean, rstd, param_partials,
-                                                                                 (int)N, E, per_slice, cb, hw, sample_sums);
+                                                                                 (int)N, E, per_slice, cb, hw, sample_sums, clC);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

@@ -4,67 +4,148 @@
 namespace drm {
 
 // ------------------------------------------------------------------------------------------------
-// lambda-return.  One block owns ROWS consecutive trajectories: their R/C/V values are one
-// contiguous run of ROWS*H floats in each input, so global loads and stores are fully coalesced;
-// the reverse scan itself runs from LDS, one lane per trajectory, row stride padded to an odd
-// number of words so the 64 lanes of a wave hit 64 different banks.
+// lambda-return (lib/trainer.py:217-224).  One block owns ROWS consecutive trajectories: their R/C/V
+// values are one contiguous run of ROWS*H floats in each input, moved with 16-byte accesses, four per
+// array in flight per thread; the reverse scan itself runs from LDS, one lane per trajectory, with an odd
+// row stride so the 64 lanes of a wave hit different banks.  The two products that do not depend on the
+// recurrence, gamma*(1-c) and (1-lambda)*v, are formed while loading; every operation is rounded on its
+// own, in the order of the eager fp32 expression, so results are bit-identical to the reference loop.
 // ------------------------------------------------------------------------------------------------
 template <int ROWS>
 __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict__ R, const float* __restrict__ C,
                                                           const float* __restrict__ V,
                                                           const float* __restrict__ VL, float* __restrict__ out,
                                                           int64_t B, int H, float gamma, float one_minus_lam,
-                                                          float lam) {
+                                                          float lam, int vec) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int HP = H | 1;
-    float* sR = sm;
-    float* sC = sm + ROWS * HP;
-    float* sV = sm + 2 * ROWS * HP;
+    const int HS = H | 1;                     // LDS row stride; odd H: the tile is stored exactly as it lies in memory
+    float* sA = sm;                           // r, then the returns
+    float* sD = sm + ROWS * HS;               // gamma * (1 - c)
+    float* sM = sm + 2 * ROWS * HS;           // (1 - lambda) * v
+    const int tid = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * ROWS;
     const int rows = (int)min((int64_t)ROWS, B - row0);
-    const int64_t base = row0 * H;
+    const int64_t base = row0 * H;            // a multiple of 4 floats (ROWS is)
     const int n = rows * H;
-    for (int i = threadIdx.x; i < n; i += ROWS) {
-        const int r = i / H, t = i - r * H;
-        sR[r * HP + t] = R[base + i];
-        sC[r * HP + t] = C[base + i];
-        sV[r * HP + t] = V[base + i];
+    float nxt = tid < rows ? VL[row0 + tid] : 0.f;
+    const int n4 = vec ? n >> 2 : 0;
+    const float4* R4 = reinterpret_cast<const float4*>(R + base);
+    const float4* C4 = reinterpret_cast<const float4*>(C + base);
+    const float4* V4 = reinterpret_cast<const float4*>(V + base);
+    constexpr int U = 4;
+    for (int k0 = 0; k0 < n4; k0 += ROWS * U) {
+        float4 r[U], c[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(k0 + u * ROWS + tid, n4 - 1);
+            r[u] = R4[i]; c[u] = C4[i]; v[u] = V4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = k0 + u * ROWS + tid;
+            if (i >= n4) continue;
+            const float a4[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+            const float d4[4] = {__fmul_rn(gamma, __fsub_rn(1.0f, c[u].x)), __fmul_rn(gamma, __fsub_rn(1.0f, c[u].y)),
+                                 __fmul_rn(gamma, __fsub_rn(1.0f, c[u].z)), __fmul_rn(gamma, __fsub_rn(1.0f, c[u].w))};
+            const float m4[4] = {__fmul_rn(one_minus_lam, v[u].x), __fmul_rn(one_minus_lam, v[u].y),
+                                 __fmul_rn(one_minus_lam, v[u].z), __fmul_rn(one_minus_lam, v[u].w)};
+            if (HS == H) {
+                reinterpret_cast<float4*>(sA)[i] = r[u];
+                reinterpret_cast<float4*>(sD)[i] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+                reinterpret_cast<float4*>(sM)[i] = make_float4(m4[0], m4[1], m4[2], m4[3]);
+            } else {
+                int rr = (i * 4) / H, t = i * 4 - rr * H;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = rr * HS + t;
+                    sA[pos] = a4[j]; sD[pos] = d4[j]; sM[pos] = m4[j];
+                    if (++t == H) { t = 0; ++rr; }
+                }
+            }
+        }
+    }
+    for (int e = n4 * 4 + tid; e < n; e += ROWS) {       // unaligned inputs, or the last elements of a short tile
+        const int rr = e / H, pos = rr * HS + (e - rr * H);
+        sA[pos] = R[base + e];
+        sD[pos] = __fmul_rn(gamma, __fsub_rn(1.0f, C[base + e]));
+        sM[pos] = __fmul_rn(one_minus_lam, V[base + e]);
     }
     __syncthreads();
-    if ((int)threadIdx.x < rows) {
-        float nxt = VL[row0 + threadIdx.x];
-        float* r = sR + threadIdx.x * HP;
-        const float* c = sC + threadIdx.x * HP;
-        const float* v = sV + threadIdx.x * HP;
+    if (tid < rows) {
+        float* a = sA + tid * HS;
+        const float* d = sD + tid * HS;
+        const float* m = sM + tid * HS;
+#pragma unroll 4
         for (int t = H - 1; t >= 0; --t) {
-            // every operation rounded on its own, in the order of the eager fp32 expression
-            const float disc = __fmul_rn(gamma, __fsub_rn(1.0f, c[t]));
-            const float mix = __fadd_rn(__fmul_rn(one_minus_lam, v[t]), __fmul_rn(lam, nxt));
-            nxt = __fadd_rn(r[t], __fmul_rn(disc, mix));
-            r[t] = nxt;
+            nxt = __fadd_rn(a[t], __fmul_rn(d[t], __fadd_rn(m[t], __fmul_rn(lam, nxt))));
+            a[t] = nxt;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += ROWS) {
-        const int r = i / H, t = i - r * H;
-        out[base + i] = sR[r * HP + t];
+    float4* O4 = reinterpret_cast<float4*>(out + base);
+    for (int i = tid; i < n4; i += ROWS) {
+        if (HS == H) {
+            O4[i] = reinterpret_cast<const float4*>(sA)[i];
+        } else {
+            int rr = (i * 4) / H, t = i * 4 - rr * H;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = sA[rr * HS + t];
+                if (++t == H) { t = 0; ++rr; }
+            }
+            O4[i] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    for (int e = n4 * 4 + tid; e < n; e += ROWS) {
+        const int rr = e / H;
+        out[base + e] = sA[rr * HS + (e - rr * H)];
     }
 }
 
-// Long horizons (rows no longer fit LDS): one lane per trajectory straight from global memory.
-__global__ __launch_bounds__(64) void k_lambda_return_long(const float* __restrict__ R, const float* __restrict__ C,
-                                                           const float* __restrict__ V, const float* __restrict__ VL,
-                                                           float* __restrict__ out, int64_t B, int H, float gamma,
-                                                           float one_minus_lam, float lam) {
-    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    float nxt = VL[b];
-    for (int t = H - 1; t >= 0; --t) {
-        const int64_t i = b * H + t;
-        const float disc = __fmul_rn(gamma, __fsub_rn(1.0f, C[i]));
-        const float mix = __fadd_rn(__fmul_rn(one_minus_lam, V[i]), __fmul_rn(lam, nxt));
-        nxt = __fadd_rn(R[i], __fmul_rn(disc, mix));
-        out[i] = nxt;
+// Longer horizons: one wave owns 64 trajectories and walks their time axis backwards in chunks of 32 steps
+// (128 contiguous bytes per trajectory and array), carrying the running return in a register.
+__global__ __launch_bounds__(64) void k_lambda_return_chunked(const float* __restrict__ R, const float* __restrict__ C,
+                                                              const float* __restrict__ V, const float* __restrict__ VL,
+                                                              float* __restrict__ out, int64_t B, int H, float gamma,
+                                                              float one_minus_lam, float lam) {
+    constexpr int TC = 32, TS = 33;
+    __shared__ float sA[64 * TS], sD[64 * TS], sM[64 * TS];
+    const int lane = threadIdx.x, tl = lane & 31, rh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)min((int64_t)64, B - row0);
+    float nxt = lane < rows ? VL[row0 + lane] : 0.f;
+    for (int t1 = H; t1 > 0; t1 -= TC) {
+        const int t0 = max(t1 - TC, 0), w = t1 - t0;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const int rr = 2 * k + rh;
+            if (rr < rows && tl < w) {
+                const int64_t idx = (row0 + rr) * H + t0 + tl;
+                const int pos = rr * TS + tl;
+                sA[pos] = R[idx];
+                sD[pos] = __fmul_rn(gamma, __fsub_rn(1.0f, C[idx]));
+                sM[pos] = __fmul_rn(one_minus_lam, V[idx]);
+            }
+        }
+        __syncthreads();
+        if (lane < rows) {
+            float* a = sA + lane * TS;
+            const float* d = sD + lane * TS;
+            const float* m = sM + lane * TS;
+#pragma unroll 4
+            for (int t = w - 1; t >= 0; --t) {
+                nxt = __fadd_rn(a[t], __fmul_rn(d[t], __fadd_rn(m[t], __fmul_rn(lam, nxt))));
+                a[t] = nxt;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const int rr = 2 * k + rh;
+            if (rr < rows && tl < w) out[(row0 + rr) * H + t0 + tl] = sA[rr * TS + tl];
+        }
+        __syncthreads();
     }
 }
 
@@ -110,9 +191,12 @@ __global__ __launch_bounds__(256) void k_seq_gather(drm_ring ring, const int64_t
 // straight-through categorical sampling over K = 32 classes.  Eight lanes own one categorical
 // (four classes each, one 16-byte access per tensor), so a wave handles eight categoricals per
 // pass and every reduction is three xor-shuffles inside the 8-lane group.
+// softmax(log_unimix(logits) - log E)_k = w_k / sum_j w_j with w_k = ((1-eps) softmax(logits)_k + eps/K) / E_k
+// (lib/world_model.py:459-461 with lib/utils.py:20-31 and F.gumbel_softmax written out): one exponential
+// and one division per class, no logarithm; the kernel then runs at memory speed instead of ALU speed.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sample_st(const float* __restrict__ logits, const float* __restrict__ expo,
-                                                    int64_t rows, float log1m_eps, float log_eps_over_k,
+                                                    int64_t rows, float one_m_eps, float eps_over_k,
                                                     int use_unimix, float* __restrict__ z_out,
                                                     uint8_t* __restrict__ idx_out, float* __restrict__ y_out) {
     const int sub = threadIdx.x & 7;
@@ -120,33 +204,29 @@ __global__ __launch_bounds__(256) void k_sample_st(const float* __restrict__ log
     for (int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); row < rows; row += stride) {
         const float4 lg = *reinterpret_cast<const float4*>(logits + row * 32 + sub * 4);
         const float4 ex = *reinterpret_cast<const float4*>(expo + row * 32 + sub * 4);
-        float v[4] = {lg.x, lg.y, lg.z, lg.w};
+        const float v[4] = {lg.x, lg.y, lg.z, lg.w};
         const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+        const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float w[4], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = expf(v[j] - mx); s += w[j]; }
         if (use_unimix) {
-            const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-            float s = 0.f;
+            const float scale = one_m_eps / group_sum<8>(s);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += expf(v[j] - mx);
-            const float lse = logf(group_sum<8>(s));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = logaddexp_f((v[j] - mx - lse) + log1m_eps, log_eps_over_k);
+            for (int j = 0; j < 4; ++j) w[j] = fmaf(w[j], scale, eps_over_k);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] - logf(e[j]);
-        const float smax = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-        float y[4], s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { y[j] = expf(v[j] - smax); s += y[j]; }
-        s = group_sum<8>(s);
         float best = -1.f;
         int bi = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j] = y[j] / s;
-            if (y[j] > best) { best = y[j]; bi = sub * 4 + j; }
+            w[j] = w[j] / fmaxf(e[j], 1e-30f);
+            if (w[j] > best) { best = w[j]; bi = sub * 4 + j; }
         }
         group_argmax<8>(best, bi);
-        if (y_out) *reinterpret_cast<float4*>(y_out + row * 32 + sub * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        if (y_out) {
+            const float inv = 1.0f / group_sum<8>((w[0] + w[1]) + (w[2] + w[3]));
+            *reinterpret_cast<float4*>(y_out + row * 32 + sub * 4) = make_float4(w[0] * inv, w[1] * inv, w[2] * inv, w[3] * inv);
+        }
         if (z_out) {
             const int k0 = sub * 4;
             *reinterpret_cast<float4*>(z_out + row * 32 + k0) =
@@ -178,18 +258,16 @@ extern "C" int drm_lambda_return(const float* R, const float* C, const float* V,
     DRM_REQUIRE(R && C && V && V_last && out, DRM_EINVAL, "null pointer");
     DRM_REQUIRE(B >= 0 && H >= 1, DRM_EINVAL, "bad shape B=%lld H=%d", (long long)B, H);
     if (B == 0) return DRM_OK;
-    const int HP = H | 1;
+    const int HS = H | 1;
     const float g = (float)gamma, oml = (float)(1.0 - lam), l = (float)lam;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PC_LAMBDA, s, 6.0 * B * H, 16.0 * B * H + 4.0 * B);
-    if ((size_t)3 * 256 * HP * 4 <= 64 * 1024) {
-        const size_t sh = (size_t)3 * 256 * HP * 4;
-        k_lambda_return<256><<<dim3((unsigned)((B + 255) / 256)), dim3(256), sh, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
-    } else if ((size_t)3 * 64 * HP * 4 <= 64 * 1024) {
-        const size_t sh = (size_t)3 * 64 * HP * 4;
-        k_lambda_return<64><<<dim3((unsigned)((B + 63) / 64)), dim3(64), sh, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
+    const size_t sh = (size_t)3 * 256 * HS * 4;
+    if (sh <= 64 * 1024) {
+        const int vec = aligned16(R) && aligned16(C) && aligned16(V) && aligned16(out);
+        k_lambda_return<256><<<dim3((unsigned)((B + 255) / 256)), dim3(256), sh, s>>>(R, C, V, V_last, out, B, H, g, oml, l, vec);
     } else {
-        k_lambda_return_long<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
+        k_lambda_return_chunked<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
     }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -226,13 +304,13 @@ extern "C" int drm_sample_categorical_st(const float* logits, const float* expo,
                 "pointers must be 16-byte aligned");
     if (rows == 0) return DRM_OK;
     const int use = unimix_eps >= 0.f;
-    const float l1m = use ? (float)log1p(-(double)unimix_eps) : 0.f;
-    const float lek = use ? (float)(log((double)unimix_eps) - log(32.0)) : 0.f;
+    const float ome = use ? 1.0f - unimix_eps : 1.f;
+    const float eok = use ? unimix_eps / 32.0f : 0.f;
     const int64_t blocks = (rows + 31) / 32;
     const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-    ProfScope prof(PC_SAMPLE, (hipStream_t)stream, 40.0 * rows * 32,
+    ProfScope prof(PC_SAMPLE, (hipStream_t)stream, 12.0 * rows * 32,
                    (double)rows * (256.0 + (z_out ? 128.0 : 0.0) + (y_out ? 128.0 : 0.0) + (idx_out ? 1.0 : 0.0)));
-    k_sample_st<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(logits, expo, rows, l1m, lek, use, z_out, idx_out, y_out);
+    k_sample_st<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(logits, expo, rows, ome, eok, use, z_out, idx_out, y_out);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

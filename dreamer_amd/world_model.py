@@ -138,7 +138,7 @@ class _ConvBiasFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.conf = (transposed, stride, padding)
         if (transposed and weight.shape[1] <= 4 and tuple(weight.shape[2:]) == (4, 4) and tuple(stride) == (2, 2)
-                and tuple(padding) == (1, 1) and x.dtype == torch.float32 and _ConvBiasFn.native_convt):
+                and tuple(padding) == (1, 1) and x.dtype == torch.float32 and _ConvBiasFn.native_convt and x.is_contiguous()):
             # few output channels: a stream, served by the library's direct kernel (bias included)
             from . import _native as N
             return N.convt_k4s2_forward(x.contiguous(), weight.contiguous(), bias)
@@ -183,7 +183,8 @@ class _LayerNormSiLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, cbias=None):
         from . import _native as N
-        x = x.contiguous()
+        if not N._is_channels_last(x):
+            x = x.contiguous()
         y, mean, rstd = N.ln_silu_forward(x, weight, bias, eps, cbias)
         ctx.save_for_backward(x, weight, bias, mean, rstd, cbias)
         return y
@@ -192,10 +193,11 @@ class _LayerNormSiLUFn(torch.autograd.Function):
     def backward(ctx, dy):
         from . import _native as N
         x, weight, bias, mean, rstd, cbias = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last) if N._is_channels_last(x) else dy.contiguous()
         if cbias is None:
-            dx, dparams = N.ln_silu_backward(x, dy.contiguous(), weight, bias, mean, rstd)
+            dx, dparams = N.ln_silu_backward(x, dy, weight, bias, mean, rstd)
             return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None, None
-        dx, dparams, dcb = N.ln_silu_backward(x, dy.contiguous(), weight, bias, mean, rstd, cbias)
+        dx, dparams, dcb = N.ln_silu_backward(x, dy, weight, bias, mean, rstd, cbias)
         return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None, dcb
 
 
@@ -211,6 +213,10 @@ class _Tower(nn.Sequential):
     are those of the plain Sequential."""
 
     fuse = os.environ.get("DRM_NO_LN_FUSION", "0") != "1"
+    # opt-in: activations of the tower in the channels-last memory format; parameters and results keep their
+    # logical (N, C, H, W) meaning.  Measured on the 16 x 64 training update: 10.70 ms against 10.81 ms with
+    # plain NCHW activations, inside the run-to-run spread, so NCHW stays the default.
+    channels_last = os.environ.get("DRM_TOWER_CHANNELS_LAST", "0") == "1"
 
     @staticmethod
     def _fusable(m, nxt, shape, x):
@@ -222,6 +228,8 @@ class _Tower(nn.Sequential):
         i = 0
         if not self.fuse or not x.is_cuda:
             return super().forward(x)
+        if self.channels_last and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] >= 64:
+            x = x.contiguous(memory_format=torch.channels_last)
         while i < len(mods):
             m = mods[i]
             if (isinstance(m, (_Conv2d, _ConvTranspose2d)) and m.bias is not None and i + 2 < len(mods)
@@ -230,10 +238,15 @@ class _Tower(nn.Sequential):
                 shape = (x.shape[0],) + tuple(ln.normalized_shape)
                 hw = shape[2] * shape[3] if len(shape) == 4 else 0
                 if self._fusable(ln, mods[i + 2], shape, x) and hw % 4 == 0 and shape[1] == m.out_channels:
-                    x = _LayerNormSiLUFn.apply(_conv_no_bias(m, x), ln.weight, ln.bias, ln.eps, m.bias)
+                    y = _conv_no_bias(m, x)
+                    if shape[1] % 4 != 0:
+                        y = y.contiguous()     # the channels-last kernels take channel counts that are multiples of 4
+                    x = _LayerNormSiLUFn.apply(y, ln.weight, ln.bias, ln.eps, m.bias)
                     i += 3
                     continue
             if i + 1 < len(mods) and self._fusable(m, mods[i + 1], tuple(x.shape), x):
+                if x.shape[1] % 4 != 0:
+                    x = x.contiguous()
                 x = _LayerNormSiLUFn.apply(x, m.weight, m.bias, m.eps)
                 i += 2
             else:

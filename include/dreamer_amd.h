@@ -345,13 +345,18 @@ int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io,
  * needs sample_sums (2N floats, scratch) and writes param_partials (slices, 3, E); the third row summed
  * over slices and over the hw positions of a channel is d b[c].  sample_sums without a channel bias
  * also selects the three-row form: the third row summed over slices is sum_n dx[n, e], the bias
- * gradient of a Linear in front of nn.LayerNorm(E) + nn.SiLU (the MLP blocks of lib/world_model.py:153-160). */
+ * gradient of a Linear in front of nn.LayerNorm(E) + nn.SiLU (the MLP blocks of lib/world_model.py:153-160).
+ * channels_last != 0: x, y, dy, dx hold each sample as (H*W positions) x (C = E / hw channels), the memory
+ * format the convolution backend serves fastest; gamma, beta and every row of param_partials stay in the
+ * module's (C, H, W) order. C must be a multiple of 4. */
 int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, drm_stream_t stream);
+                        int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, int32_t channels_last,
+                        drm_stream_t stream);
 int32_t drm_ln_silu_slices(int64_t N, int32_t E);
 int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                          const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E,
-                         const float* channel_bias, int32_t hw, float* sample_sums, drm_stream_t stream);
+                         const float* channel_bias, int32_t hw, int32_t channels_last, float* sample_sums,
+                         drm_stream_t stream);
 
 #ifdef __cplusplus
 }

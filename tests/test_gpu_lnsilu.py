@@ -83,3 +83,54 @@ def test_fused_mlp_block_matches_linear_layer_norm_silu(rows, k, width):
     assert rel(out, ref) < 5e-6
     for name, a, r in zip("x w b gamma beta".split(), g_out, g_ref):
         assert rel(a, r) < 3e-5, name
+
+
+@pytest.mark.parametrize("N,C,HW,with_cb", [(64, 32, (32, 32), True), (9, 8, (4, 4), True), (130, 16, (8, 8), False), (3, 4, (2, 3), True),
+                                            (5, 256, (4, 4), False)])
+def test_channels_last_samples_match_torch(N, C, HW, with_cb):
+    """The same block on channels-last activations (parameters stay in (C, H, W) order)."""
+    g = torch.Generator().manual_seed(N + C)
+    shape = (C, *HW)
+    x = (torch.randn(N, *shape, generator=g) * 1.3).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (1.0 + 0.2 * torch.randn(*shape, generator=g)).to(DEV).requires_grad_(True)
+    b = (0.1 * torch.randn(*shape, generator=g)).to(DEV).requires_grad_(True)
+    cb = (0.5 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    dy = torch.randn(N, *shape, generator=g).to(DEV)
+    pre = x + cb.view(1, C, 1, 1) if with_cb else x
+    ref = F.silu(F.layer_norm(pre, shape, w, b, 1e-5))
+    wrt = (x, w, b, cb) if with_cb else (x, w, b)
+    g_ref = torch.autograd.grad(ref, wrt, dy)
+    out = _LayerNormSiLUFn.apply(x, w, b, 1e-5, cb if with_cb else None)
+    assert out.is_contiguous(memory_format=torch.channels_last)
+    g_out = torch.autograd.grad(out, wrt, dy)
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / (r.double().abs().max() + 1e-30))
+    assert rel(out, ref) < 2e-6
+    for name, a, r in zip("x gamma beta cbias".split(), g_out, g_ref):
+        assert rel(a, r) < (5e-5 if name == "cbias" else 1e-5), name
+
+
+@pytest.mark.parametrize("which", ["encoder", "decoder"])
+def test_channels_last_towers_match_plain_sequential(monkeypatch, which):
+    from dreamer_amd import world_model as W
+    torch.manual_seed(4)
+    n = 70
+    if which == "encoder":
+        mod = W.Encoder((3, 64, 64), base_cnn_channels=8).to(DEV).conv
+        args = (torch.rand(n, 3, 64, 64, device=DEV),)
+        fn = lambda: mod(*args)
+    else:
+        dec = W.Decoder((3, 64, 64), base_cnn_channels=8, num_latents=8, hidden_size=64).to(DEV)
+        h = torch.randn(n, 64, device=DEV)
+        z = F.one_hot(torch.randint(0, 32, (n, 8), device=DEV), 32).float()
+        mod, fn = dec, (lambda: dec(h, z))
+    monkeypatch.setattr(W._Tower, "fuse", False)
+    ref = fn()
+    g_ref = torch.autograd.grad(ref.square().sum(), list(mod.parameters()))
+    monkeypatch.setattr(W._Tower, "fuse", True)
+    monkeypatch.setattr(W._Tower, "channels_last", True)
+    out = fn()
+    g_out = torch.autograd.grad(out.square().sum(), list(mod.parameters()))
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / (r.double().abs().max() + 1e-30))
+    assert out.shape == ref.shape and rel(out, ref) < 1e-5
+    for (name, _), a, r in zip(mod.named_parameters(), g_out, g_ref):
+        assert rel(a, r) < 2e-4, name

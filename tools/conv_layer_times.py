@@ -7,6 +7,7 @@ import torch.nn.functional as F
 torch.backends.cudnn.benchmark = True
 dev = torch.device("cuda:0")
 N = 1024
+CL = len(sys.argv) > 1 and sys.argv[1] == "channels_last"   # NHWC memory format for inputs, weights and gradients
 
 
 def timed(fn, reps=10):
@@ -26,9 +27,14 @@ for name, tr, cin, cout, hin in layers:
     x = torch.randn(N, cin, hin, hin, device=dev, requires_grad=True)
     w = torch.randn((cin, cout, 4, 4) if tr else (cout, cin, 4, 4), device=dev, requires_grad=True) * 0.05
     w = w.detach().requires_grad_(True)
+    if CL:
+        x = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        w = w.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     f = (lambda: F.conv_transpose2d(x, w, None, 2, 1)) if tr else (lambda: F.conv2d(x, w, None, 2, 1))
     y = f()
     g = torch.randn_like(y)
+    if CL:
+        g = g.contiguous(memory_format=torch.channels_last)
     t_f = timed(f)
     t_fb = timed(lambda: torch.autograd.grad(f(), (x, w), g))
     t_fw = timed(lambda: torch.autograd.grad(f(), (w,), g))
