@@ -511,12 +511,12 @@ __global__ __launch_bounds__(256) void k_sample_rows(const SampleRowsArgs P) {
         float pj[4], s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pj[j] = expf(v[j] - mx); s += pj[j]; }
-        const float scale = P.one_m_eps / group_sum<8>(s);
+        const float scale = P.one_m_eps * __builtin_amdgcn_rcpf(group_sum<8>(s));
         float best = -1.f;
         int bi = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float q = fmaf(pj[j], scale, P.eps_over_k) / e[j];
+            const float q = fmaf(pj[j], scale, P.eps_over_k) * __builtin_amdgcn_rcpf(e[j]);   // reciprocal within 1 ulp
             if (q > best) { best = q; bi = sub * 4 + j; }
         }
         group_argmax<8>(best, bi);

@@ -150,11 +150,22 @@ __global__ __launch_bounds__(64) void k_lambda_return_chunked(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// replay sequence gather.  One block per (b, t) frame: 16-byte lane accesses, consecutive lanes on
-// consecutive 16-byte chunks (1 KiB per wave instruction).  Lane 0 moves the three scalars.
-// The optional fp32 image is produced in a second sweep over the frame with 4-byte loads and
-// 16-byte stores so that the stores are contiguous across the wave as well.
+// replay sequence gather (lib/replay_buffer.py:46-85).  One block per (b, t) frame.  Bytes only: 16-byte
+// lane accesses, consecutive lanes on consecutive chunks (1 KiB per wave instruction), four loads in flight
+// per thread before the first store.  With the fp32 image (lib/trainer.py:163, obs.float() / 255) the frame is
+// read once in 4-byte words (256 contiguous bytes per wave instruction); each word is stored as it is and
+// as one 16-byte group of four floats, so both outputs are written contiguously across the wave.
+// Lane 0 moves the three scalars.
 // ------------------------------------------------------------------------------------------------
+// x / 255 correctly rounded for x = 0..255 without the division sequence: q = x * fl(1/255), one exact
+// residual and one correction (equal to the IEEE quotient for all 256 inputs)
+__device__ __forceinline__ float byte_over_255(uint32_t x) {
+    const float r = 1.0f / 255.0f;
+    const float f = (float)x;
+    const float q = __fmul_rn(f, r);
+    return fmaf(fmaf(-q, 255.0f, f), r, q);
+}
+
 __global__ __launch_bounds__(256) void k_seq_gather(drm_ring ring, const int64_t* __restrict__ starts, int T,
                                                      uint8_t* __restrict__ obs_out, int64_t* __restrict__ act_out,
                                                      float* __restrict__ rew_out, uint8_t* __restrict__ cont_out,
@@ -162,28 +173,46 @@ __global__ __launch_bounds__(256) void k_seq_gather(drm_ring ring, const int64_t
     const int64_t frame = blockIdx.x;  // b*T + t
     const int b = (int)(frame / T), t = (int)(frame - (int64_t)b * T);
     const int64_t src = (starts[b] + t) % ring.capacity;
-    const uint4* s16 = reinterpret_cast<const uint4*>(ring.observations + src * ring.frame_bytes);
-    uint4* d16 = reinterpret_cast<uint4*>(obs_out + frame * ring.frame_bytes);
-    const int n16 = (int)(ring.frame_bytes >> 4);
-    for (int i = threadIdx.x; i < n16; i += 256) d16[i] = s16[i];
-    if (threadIdx.x == 0) {
+    const int tid = threadIdx.x;
+    constexpr int U = 4;
+    if (obs_f32 == nullptr) {
+        const uint4* s16 = reinterpret_cast<const uint4*>(ring.observations + src * ring.frame_bytes);
+        uint4* d16 = reinterpret_cast<uint4*>(obs_out + frame * ring.frame_bytes);
+        const int n16 = (int)(ring.frame_bytes >> 4);
+        for (int k0 = 0; k0 < n16; k0 += 256 * U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = s16[min(k0 + u * 256 + tid, n16 - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = k0 + u * 256 + tid;
+                if (i < n16) d16[i] = v[u];
+            }
+        }
+    } else {
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(ring.observations + src * ring.frame_bytes);
+        uint32_t* d4 = reinterpret_cast<uint32_t*>(obs_out + frame * ring.frame_bytes);
+        float4* d = reinterpret_cast<float4*>(obs_f32 + frame * ring.frame_bytes);
+        const int n4 = (int)(ring.frame_bytes >> 2);
+        for (int k0 = 0; k0 < n4; k0 += 256 * U) {
+            uint32_t w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = s4[min(k0 + u * 256 + tid, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = k0 + u * 256 + tid;
+                if (i < n4) {
+                    d4[i] = w[u];
+                    d[i] = make_float4(byte_over_255(w[u] & 0xffu), byte_over_255((w[u] >> 8) & 0xffu),
+                                       byte_over_255((w[u] >> 16) & 0xffu), byte_over_255(w[u] >> 24));
+                }
+            }
+        }
+    }
+    if (tid == 0) {
         act_out[frame] = ring.actions[src];
         rew_out[frame] = ring.rewards[src];
         cont_out[frame] = ring.continues[src];
-    }
-    if (obs_f32 != nullptr) {
-        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s16);
-        float4* d = reinterpret_cast<float4*>(obs_f32 + frame * ring.frame_bytes);
-        const int n4 = (int)(ring.frame_bytes >> 2);
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            const uint32_t w = s4[i];
-            float4 f;
-            f.x = __fdiv_rn((float)(w & 0xffu), 255.0f);
-            f.y = __fdiv_rn((float)((w >> 8) & 0xffu), 255.0f);
-            f.z = __fdiv_rn((float)((w >> 16) & 0xffu), 255.0f);
-            f.w = __fdiv_rn((float)(w >> 24), 255.0f);
-            d[i] = f;
-        }
     }
 }
 
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(256) void k_sample_st(const float* __restrict__ log
 #pragma unroll
         for (int j = 0; j < 4; ++j) { w[j] = expf(v[j] - mx); s += w[j]; }
         if (use_unimix) {
-            const float scale = one_m_eps / group_sum<8>(s);
+            const float scale = one_m_eps * __builtin_amdgcn_rcpf(group_sum<8>(s));
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = fmaf(w[j], scale, eps_over_k);
         }
@@ -219,12 +248,12 @@ __global__ __launch_bounds__(256) void k_sample_st(const float* __restrict__ log
         int bi = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            w[j] = w[j] / fmaxf(e[j], 1e-30f);
+            w[j] = w[j] * __builtin_amdgcn_rcpf(fmaxf(e[j], 1e-30f));   // reciprocal within 1 ulp
             if (w[j] > best) { best = w[j]; bi = sub * 4 + j; }
         }
         group_argmax<8>(best, bi);
         if (y_out) {
-            const float inv = 1.0f / group_sum<8>((w[0] + w[1]) + (w[2] + w[3]));
+            const float inv = __builtin_amdgcn_rcpf(group_sum<8>((w[0] + w[1]) + (w[2] + w[3])));
             *reinterpret_cast<float4*>(y_out + row * 32 + sub * 4) = make_float4(w[0] * inv, w[1] * inv, w[2] * inv, w[3] * inv);
         }
         if (z_out) {
@@ -307,7 +336,8 @@ extern "C" int drm_sample_categorical_st(const float* logits, const float* expo,
     const float ome = use ? 1.0f - unimix_eps : 1.f;
     const float eok = use ? unimix_eps / 32.0f : 0.f;
     const int64_t blocks = (rows + 31) / 32;
-    const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+    // one pass per block while the grid fits: consecutive blocks then sweep memory as one moving window
+    const unsigned grid = (unsigned)(blocks < (1 << 24) ? blocks : (1 << 24));
     ProfScope prof(PC_SAMPLE, (hipStream_t)stream, 12.0 * rows * 32,
                    (double)rows * (256.0 + (z_out ? 128.0 : 0.0) + (y_out ? 128.0 : 0.0) + (idx_out ? 1.0 : 0.0)));
     k_sample_st<<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(logits, expo, rows, ome, eok, use, z_out, idx_out, y_out);

@@ -1,22 +1,28 @@
 """Achieved HBM bandwidth of the three stream kernels (replay sequence gather, straight-through categorical
 sampling, lambda-return scan) at sizes that fill the device, beside the sizes of the default configuration.
 
-    python tools/bench_stream.py [out.json]
+    python tools/bench_stream.py [out.json] [--large-only]
+
+--large-only runs one device-filling case per kernel (the cases a kernel trace or a counter pass of this
+command is read against: every launch of a kernel then has the same size).
 
 Bytes are the algorithmic ones (every input read once, every output written once); time is the mean of
 back-to-back launches between two events on the launch stream.  Peak: 8 TB/s.
 """
 import ctypes as C
 import json
+import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreamer_amd import _native as N  # noqa: E402
 
 PEAK_GBS = 8000.0
+LARGE = "--large-only" in sys.argv
+ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
 dev = torch.device("cuda:0")
 L = N.lib()
 S = lambda: N.stream_ptr(dev)
@@ -54,7 +60,8 @@ rew = torch.randn(cap, device=dev, generator=g)
 con = torch.rand(cap, device=dev, generator=g) > 0.01
 ring = N.drm_ring(obs.data_ptr(), act.data_ptr(), rew.data_ptr(), con.data_ptr(), cap, frame)
 rs = np.random.RandomState(42)
-for B, T, f32 in ((16, 64, False), (16, 64, True), (256, 64, False), (256, 64, True), (1024, 64, False)):
+for B, T, f32 in (((1024, 64, False),) if LARGE else
+                  ((16, 64, False), (16, 64, True), (256, 64, False), (256, 64, True), (1024, 64, False))):
     starts = torch.from_numpy(rs.randint(0, cap, size=B)).to(dev)
     o = torch.empty((B, T, 3, 64, 64), dtype=torch.uint8, device=dev)
     a = torch.empty((B, T), dtype=torch.int64, device=dev)
@@ -71,8 +78,9 @@ for B, T, f32 in ((16, 64, False), (16, 64, True), (256, 64, False), (256, 64, T
 del obs
 
 # ---------------------------------------------------------------- categorical sampling (K = 32)
-for rows, wz, wi, wy in ((16 * 32, True, True, False), (61440 * 32, True, True, False), (61440 * 32, False, True, False),
-                         (61440 * 32, True, True, True), (4 * 61440 * 32, True, True, False)):
+for rows, wz, wi, wy in (((4 * 61440 * 32, True, True, False),) if LARGE else
+                        ((16 * 32, True, True, False), (61440 * 32, True, True, False), (61440 * 32, False, True, False),
+                         (61440 * 32, True, True, True), (4 * 61440 * 32, True, True, False))):
     lg = torch.randn(rows, 32, device=dev, generator=g)
     ex = torch.empty(rows, 32, device=dev).exponential_(generator=g)
     z = torch.empty_like(lg) if wz else None
@@ -88,7 +96,7 @@ for rows, wz, wi, wy in ((16 * 32, True, True, False), (61440 * 32, True, True, 
     del lg, ex, z, y
 
 # ---------------------------------------------------------------- lambda-return scan
-for B, H in ((16, 15), (4096, 15), (1 << 20, 15), (1 << 22, 15), (1 << 20, 64), (1 << 16, 333)):
+for B, H in (((1 << 22, 15),) if LARGE else ((16, 15), (4096, 15), (1 << 20, 15), (1 << 22, 15), (1 << 20, 64), (1 << 16, 333))):
     R = torch.randn(B, H, device=dev, generator=g)
     Cc = torch.rand(B, H, device=dev, generator=g)
     V = torch.randn(B, H, device=dev, generator=g)
@@ -101,6 +109,6 @@ for B, H in ((16, 15), (4096, 15), (1 << 20, 15), (1 << 22, 15), (1 << 20, 64), 
     report("k_lambda_return", f"B={B} H={H}", 16 * B * H + 4 * B, timed(fn, 50))
     del R, Cc, V, out
 
-if len(sys.argv) > 1:
-    with open(sys.argv[1], "w") as fh:
+if ARGS:
+    with open(ARGS[0], "w") as fh:
         json.dump({"peak_GB/s": PEAK_GBS, "rows": rows_out}, fh, indent=1)
