@@ -120,6 +120,7 @@ SIGNATURES = {
     "drm_copy_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_fused_linear_f32": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
+    "drm_fused_linear_split": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_pack_imagine_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
     "drm_pack_imagine": (C.c_int, [C.POINTER(drm_imagine_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
@@ -314,9 +315,11 @@ def copy_pair(a_dst: torch.Tensor, a_src: torch.Tensor, b_dst: torch.Tensor, b_s
                               stream_ptr(a_dst.device)), "drm_copy_pair")
 
 
-def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None, bf16: bool = False):
+def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None, bf16: bool = False,
+                 split: bool = False):
     """Y = f(x) @ w[:, :K]^T + bias (+ one-hot table rows).  ``w`` may be wider than K (``w_cols`` = K).
-    ``bf16``: bf16 matrix inputs with fp32 accumulation (no LayerNorm prologue)."""
+    ``bf16``: bf16 matrix inputs with fp32 accumulation (no LayerNorm prologue).
+    ``split``: fp32 accuracy from an exact three-way bf16 split of both operands (no LayerNorm prologue)."""
     require_cuda(x, w)
     M, K = x.shape
     N = w.shape[0]
@@ -335,7 +338,9 @@ def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int =
         a.latents, a.classes = zidx.shape[1], classes
     a.Y, a.ldy = y.data_ptr(), y.stride(0)
     a.M, a.N, a.K = M, N, K
-    if bf16:
+    if split:
+        check(lib().drm_fused_linear_split(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_split")
+    elif bf16:
         check(lib().drm_fused_linear_bf16(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_bf16")
     else:
         check(lib().drm_fused_linear_f32(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_f32")

@@ -644,6 +644,35 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
     }
 }
 
+// Split images of the weight operands of one imagination call (precision 2): made on first use inside the
+// call, found again by (pointer, shape) afterwards.  The area lives in the caller's workspace.
+struct SplitCache {
+    uint16_t* base; size_t capacity, used;            // in bf16 elements
+    struct Entry { const float* W; int64_t ldw; int N, K; const uint16_t* planes; } e[64];
+    int n;
+};
+static thread_local SplitCache* t_split = nullptr;
+struct SplitCacheScope {
+    SplitCacheScope(SplitCache* c) { t_split = c; }
+    ~SplitCacheScope() { t_split = nullptr; }
+};
+static const uint16_t* split_planes_of(const ProblemSpec& q, hipStream_t stream) {
+    SplitCache* c = t_split;
+    if (c == nullptr) return nullptr;
+    for (int i = 0; i < c->n; ++i)
+        if (c->e[i].W == q.W && c->e[i].ldw == q.ldw && c->e[i].N == q.N && c->e[i].K == q.K) return c->e[i].planes;
+    const size_t need = (size_t)3 * q.N * q.K;
+    if (c->n >= 64 || c->used + need > c->capacity) return nullptr;
+    uint16_t* planes = c->base + c->used;
+    const int64_t total4 = (int64_t)q.N * q.K / 4;
+    const int64_t blocks = (total4 + 255) / 256;
+    k_split_planes<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream>>>(q.W, q.ldw, q.N, q.K, planes);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    c->e[c->n++] = {q.W, q.ldw, q.N, q.K, planes};
+    c->used += need;
+    return planes;
+}
+
 int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                hipStream_t stream, int precision) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
@@ -653,7 +682,7 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
     // 64-column tiles when 128-column ones would give fewer than two workgroups per CU (fp32 form)
     int tiles128 = 0;
     for (int i = 0; i < np; ++i) tiles128 += (specs[i].N + BIG_BN - 1) / BIG_BN;
-    const bool narrow = precision != 1 && (int64_t)tiles128 * ((M + BIG_BM - 1) / BIG_BM) < 512 &&
+    const bool narrow = precision == 0 && (int64_t)tiles128 * ((M + BIG_BM - 1) / BIG_BM) < 512 &&
                         std::getenv("DRM_NO_NARROW_TILES") == nullptr;
     const int bn = narrow ? BIG_BN64 : BIG_BN;
     for (int i = 0; i < np; ++i) {
@@ -671,9 +700,15 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
         by += 4.0 * (m * k + n * k + n + m * n) + (q.tab ? 4.0 * latents * classes * n + (double)latents * m : 0.0);
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
+    bool presplit = precision == 2;
+    if (presplit) {   // before the timed scope: the images are made once and serve every later launch of the call
+        for (int i = 0; i < np && presplit; ++i) presplit = (L.p[i].Ws = split_planes_of(specs[i], stream)) != nullptr;
+    }
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
     const dim3 grid(tiles, (M + BIG_BM - 1) / BIG_BM);
     if (precision == 1) k_linear_big_bf16<<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 2 && presplit) k_linear_big_split<true><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 2) k_linear_big_split<false><<<grid, dim3(256), 0, stream>>>(L);
     else if (narrow) k_linear_big64<<<grid, dim3(256), 0, stream>>>(L);
     else k_linear_big<<<grid, dim3(256), 0, stream>>>(L);
     DRM_LAUNCH_CHECK();
@@ -724,7 +759,7 @@ static PackLayout pack_layout(const drm_dims& d) {
 }
 
 struct WsLayout {
-    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, gi, logits, act[3], a1h, xz, total;   // offsets in floats
+    size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, gi, logits, act[3], a1h, xz, split, split_floats, total;   // offsets in floats
 };
 constexpr int BIG_MIN_ROWS = 256;   // from this many trajectories on, the MFMA-bound large-row kernels are used
 static WsLayout ws_layout(const drm_dims& d, int B, int H) {
@@ -743,6 +778,12 @@ static WsLayout ws_layout(const drm_dims& d, int B, int H) {
         w.gi = take((size_t)B * 3 * d.D);
         w.logits = take((size_t)B * d.L * d.K);
         for (int i = 0; i < 3; ++i) w.act[i] = take(rows * d.M);
+        // three bf16 images of every weight the large-row GEMMs read (precision 2): 1.5 floats per element
+        const size_t S = (size_t)d.D + (size_t)d.L * d.K;
+        const size_t welems = 5 * (S * d.M + 3 * (size_t)d.M * d.M) + (size_t)d.L * d.K * d.M + 256 * (size_t)d.M +
+                              6 * (size_t)d.D * d.D + (size_t)d.D * S;
+        w.split_floats = (welems * 3 + 1) / 2;
+        w.split = take(w.split_floats);
     }
     if (B <= SKINNY_MAX_ROWS && !wide) {
         w.gi = take((size_t)B * 3 * d.D);
@@ -826,6 +867,14 @@ extern "C" int drm_fused_linear_bf16(const drm_linear_args* a, drm_stream_t stre
     return launch_big(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream, 1);
 }
 
+extern "C" int drm_fused_linear_split(const drm_linear_args* a, drm_stream_t stream) {
+    DRM_REQUIRE(a, DRM_EINVAL, "null args");
+    DRM_REQUIRE(a->M >= 1 && a->ln_gamma == nullptr, DRM_EINVAL, "M=%d; the split product takes activated inputs", a->M);
+    DRM_REQUIRE(!a->table || (a->classes >= 1 && a->latents >= 1), DRM_EINVAL, "bad gather shape");
+    ProblemSpec s{a->X, a->ldx, nullptr, nullptr, a->W, a->ldw, a->bias, a->table, a->ldt, a->Y, a->ldy, a->N, a->K};
+    return launch_big(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream, 2);
+}
+
 extern "C" size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H) {
     if (!dims || check_dims(*dims) != DRM_OK || B < 1 || H < 1) return 0;
     return ws_layout(*dims, B, H).total * sizeof(float);
@@ -876,11 +925,18 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const float l1m = (float)log1p(-(double)d.unimix_eps);
     const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
     const float lea = (float)(log((double)d.unimix_eps) - log((double)d.A));
-    DRM_REQUIRE(io->precision == 0 || io->precision == 1, DRM_EINVAL, "precision=%d", io->precision);
+    DRM_REQUIRE(io->precision >= 0 && io->precision <= 2, DRM_EINVAL, "precision=%d", io->precision);
     const int prec = io->precision;
     const bool wide = D > 512 || M > 512;                // beyond the register-resident small-row kernels
     const bool big = B >= BIG_MIN_ROWS || wide;
     float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
+
+    SplitCache split_cache{};
+    if (prec == 2 && big) {
+        split_cache.base = reinterpret_cast<uint16_t*>(ws + wl.split);
+        split_cache.capacity = wl.split_floats * 2;
+    }
+    SplitCacheScope split_scope(prec == 2 && big ? &split_cache : nullptr);
 
     const bool few = B <= SKINNY_MAX_ROWS && !wide;
     if (few) {

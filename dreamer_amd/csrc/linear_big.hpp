@@ -27,6 +27,7 @@ struct BigProblem {
     float* Y; int64_t ldy;
     int N, K;
     int tile_begin;                  // first blockIdx.x (column tile) of this problem
+    const uint16_t* Ws = nullptr;    // split form only: W as three bf16 images [3][N][K] (k_split_planes), or nullptr
 };
 
 struct BigLaunch {
@@ -512,6 +513,231 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
             if (n + 2 < P.N) out[2] = y.z;
             if (n + 3 < P.N) out[3] = y.w;
         }
+    }
+}
+
+// ---- fp32 products on the bf16 matrix pipe: exact three-way split -----------------------------------
+// Every fp32 operand is split exactly into three bf16 parts, a = h + m + l (h = bf16(a), m = bf16(a - h),
+// l = bf16(a - h - m): 8 + 8 + 8 mantissa bits, both residuals exact), on its way into LDS.  The product
+// a*b is accumulated from the six partial products hh' + hm' + mh' + hl' + lh' + mm' (each exact in fp32);
+// the three dropped ones are below 2^-24 |a b|, i.e. below the rounding of an fp32 product.  Accumulation
+// is fp32 as in k_linear_big, so results agree with the fp32 form to fp32 rounding, while the matrix pipe
+// runs v_mfma_f32_32x32x16_bf16: 6 of them cover the k range of 48 v_mfma_f32_32x32x2_f32 at an eighth of
+// the passes each, a third of the matrix-pipe time of the fp32 form.
+// Same 64 x 128 tile, wave layout and epilogue as k_linear_big_bf16; one LDS stage (three bf16 images per
+// operand, 46 KB), the next K-step's global loads in flight in registers during the MFMAs.
+// PRESPLIT: the weight operand comes from three bf16 images made once per call by k_split_planes (weights are
+// shared by every row tile and every step of a rollout), so only the activation operand is split here.
+template <bool PRESPLIT>
+__global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
+    constexpr int A_PART = BIG_BM * BIG_LDH, B_PART = BIG_BN * BIG_LDH;
+    __shared__ __attribute__((aligned(16))) __bf16 smem_h[3 * A_PART + 3 * B_PART];      // 46,080 B >= 64 x 132 floats
+    static_assert(sizeof(__bf16) * (3 * A_PART + 3 * B_PART) >= sizeof(float) * BIG_BM * (BIG_BN + 4), "epilogue tile");
+    __bf16 (*sA)[BIG_BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BM][BIG_LDH]>(smem_h);
+    __bf16 (*sB)[BIG_BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BN][BIG_LDH]>(smem_h + 3 * A_PART);
+
+    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    int lin = blockIdx.y * nbx + blockIdx.x;
+    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+    const int bx = lin % nbx, by = lin / nbx;
+
+    int pi = L.np - 1;
+    while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
+    const BigProblem& P = L.p[pi];
+    const int n0 = (bx - P.tile_begin) * BIG_BN;
+    const int m0 = by * BIG_BM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = P.K;
+
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    const float* xa[2];
+    const float* wb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+
+    // pre-split weights: 128 rows x 32 k x 3 images = 1536 16-byte pieces per K-step, six per thread:
+    // piece j of thread t is image j / 2, row t / 4 + 64 * (j % 2), k offset 8 * (t % 4)
+    const int prow = tid >> 2, pkq = (tid & 3) * 8;
+    const uint16_t* ws0 = nullptr;
+    const uint16_t* ws1 = nullptr;
+    int64_t wplane = 0;
+    if (PRESPLIT) {
+        ws0 = P.Ws + (int64_t)min(n0 + prow, P.N - 1) * K + pkq;
+        ws1 = P.Ws + (int64_t)min(n0 + prow + 64, P.N - 1) * K + pkq;
+        wplane = (int64_t)P.N * K;
+    }
+    __bf16* const wdst = &sB[0][prow][pkq];
+
+    const int nk = K / BIG_BK;
+    float4 ra[2], rb[4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rs0, rs1, rs2, rs3, rs4, rs5;
+    rs0 = rs1 = rs2 = rs3 = rs4 = rs5 = (u32x4)(0u);
+#define BIGS_LOAD(ko)                                                       \
+    ra[0] = *reinterpret_cast<const float4*>(xa[0] + (ko));                 \
+    ra[1] = *reinterpret_cast<const float4*>(xa[1] + (ko));                 \
+    if (PRESPLIT) {                                                         \
+        rs0 = *reinterpret_cast<const u32x4*>(ws0 + (ko));                \
+        rs1 = *reinterpret_cast<const u32x4*>(ws1 + (ko));                \
+        rs2 = *reinterpret_cast<const u32x4*>(ws0 + wplane + (ko));       \
+        rs3 = *reinterpret_cast<const u32x4*>(ws1 + wplane + (ko));       \
+        rs4 = *reinterpret_cast<const u32x4*>(ws0 + 2 * wplane + (ko));   \
+        rs5 = *reinterpret_cast<const u32x4*>(ws1 + 2 * wplane + (ko));   \
+    } else {                                                                \
+        rb[0] = *reinterpret_cast<const float4*>(wb[0] + (ko));             \
+        rb[1] = *reinterpret_cast<const float4*>(wb[1] + (ko));             \
+        rb[2] = *reinterpret_cast<const float4*>(wb[2] + (ko));             \
+        rb[3] = *reinterpret_cast<const float4*>(wb[3] + (ko));             \
+    }
+#define BIGS_PUT(S, row, v)                                                 \
+    {                                                                       \
+        const float f[4] = {(v).x, (v).y, (v).z, (v).w};                    \
+        bf16x4 h, m, l;                                                     \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                     \
+            h[c] = (__bf16)f[c];                                            \
+            const float r1 = f[c] - (float)h[c];                            \
+            m[c] = (__bf16)r1;                                              \
+            l[c] = (__bf16)(r1 - (float)m[c]);                              \
+        }                                                                   \
+        *reinterpret_cast<bf16x4*>(&S[0][row][skq]) = h;                    \
+        *reinterpret_cast<bf16x4*>(&S[1][row][skq]) = m;                    \
+        *reinterpret_cast<bf16x4*>(&S[2][row][skq]) = l;                    \
+    }
+#define BIGS_FRAG(S, part, row, half) (*reinterpret_cast<const bf16x8*>(&S[part][row][(half) * 16 + lh * 8]))
+#define BIGS_MMA(a, b, acc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    // smallest partial products first; the two accumulators alternate so that consecutive MFMAs are independent
+#define BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)               \
+    BIGS_MMA(am, b0m, acc0) BIGS_MMA(am, b1m, acc1) BIGS_MMA(al, b0h, acc0) BIGS_MMA(al, b1h, acc1) \
+    BIGS_MMA(ah, b0l, acc0) BIGS_MMA(ah, b1l, acc1) BIGS_MMA(am, b0h, acc0) BIGS_MMA(am, b1h, acc1) \
+    BIGS_MMA(ah, b0m, acc0) BIGS_MMA(ah, b1m, acc1) BIGS_MMA(ah, b0h, acc0) BIGS_MMA(ah, b1h, acc1)
+
+    BIGS_LOAD(0)
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks > 0) __syncthreads();             // every wave has read the previous stage
+        BIGS_PUT(sA, srow, ra[0])
+        BIGS_PUT(sA, srow + 32, ra[1])
+        if (PRESPLIT) {
+            *reinterpret_cast<u32x4*>(wdst) = rs0;
+            *reinterpret_cast<u32x4*>(wdst + 64 * BIG_LDH) = rs1;
+            *reinterpret_cast<u32x4*>(wdst + B_PART) = rs2;
+            *reinterpret_cast<u32x4*>(wdst + B_PART + 64 * BIG_LDH) = rs3;
+            *reinterpret_cast<u32x4*>(wdst + 2 * B_PART) = rs4;
+            *reinterpret_cast<u32x4*>(wdst + 2 * B_PART + 64 * BIG_LDH) = rs5;
+        } else {
+            BIGS_PUT(sB, srow, rb[0])
+            BIGS_PUT(sB, srow + 32, rb[1])
+            BIGS_PUT(sB, srow + 64, rb[2])
+            BIGS_PUT(sB, srow + 96, rb[3])
+        }
+        __syncthreads();
+        if (ks + 1 < nk) { BIGS_LOAD((ks + 1) * BIG_BK) }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bf16x8 ah = BIGS_FRAG(sA, 0, wm * 32 + li, half), am = BIGS_FRAG(sA, 1, wm * 32 + li, half),
+                         al = BIGS_FRAG(sA, 2, wm * 32 + li, half);
+            const bf16x8 b0h = BIGS_FRAG(sB, 0, wn * 64 + li, half), b0m = BIGS_FRAG(sB, 1, wn * 64 + li, half),
+                         b0l = BIGS_FRAG(sB, 2, wn * 64 + li, half);
+            const bf16x8 b1h = BIGS_FRAG(sB, 0, wn * 64 + 32 + li, half), b1m = BIGS_FRAG(sB, 1, wn * 64 + 32 + li, half),
+                         b1l = BIGS_FRAG(sB, 2, wn * 64 + 32 + li, half);
+            BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)
+        }
+    }
+#undef BIGS_LOAD
+#undef BIGS_PUT
+#undef BIGS_FRAG
+#undef BIGS_MMA
+#undef BIGS_TWELVE
+
+    // ---- epilogue (as k_linear_big): tile through LDS, + bias, + one-hot table rows, 16-byte stores
+    __syncthreads();
+    float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem_h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = acc0[i];
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const int n = n0 + c4;
+    if (n >= P.N) return;
+    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias) {
+        bias.x = P.bias[n];
+        if (n + 1 < P.N) bias.y = P.bias[n + 1];
+        if (n + 2 < P.N) bias.z = P.bias[n + 2];
+        if (n + 3 < P.N) bias.w = P.bias[n + 3];
+    }
+    for (int r = tid >> 5; r < BIG_BM; r += 8) {
+        const int m = m0 + r;
+        if (m >= L.M) break;
+        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
+        if (P.tab != nullptr) {
+            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
+            if (vec) {
+                for (int l = 0; l < L.latents; l += 8) {
+                    float4 u[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ll = min(l + j, L.latents - 1);
+                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
+                }
+            } else {
+                for (int l = 0; l < L.latents; ++l) {
+                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
+                    y.x += tb[0];
+                    if (n + 1 < P.N) y.y += tb[1];
+                    if (n + 2 < P.N) y.z += tb[2];
+                    if (n + 3 < P.N) y.w += tb[3];
+                }
+            }
+        }
+        float* out = P.Y + (int64_t)m * P.ldy + n;
+        if (vec) {
+            *reinterpret_cast<float4*>(out) = y;
+        } else {
+            out[0] = y.x;
+            if (n + 1 < P.N) out[1] = y.y;
+            if (n + 2 < P.N) out[2] = y.z;
+            if (n + 3 < P.N) out[3] = y.w;
+        }
+    }
+}
+
+// W (N, K) with row stride ldw -> three bf16 images [3][N][K]: h = bf16(w), m = bf16(w - h), l = bf16(w - h - m)
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ W, int64_t ldw, int N, int K,
+                                                       uint16_t* __restrict__ planes) {
+    const int64_t total4 = (int64_t)N * K / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int n = (int)(e / K), k = (int)(e - (int64_t)n * K);
+        const float4 v = *reinterpret_cast<const float4*>(W + (int64_t)n * ldw + k);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            h[c] = (__bf16)f[c];
+            const float r1 = f[c] - (float)h[c];
+            m[c] = (__bf16)r1;
+            l[c] = (__bf16)(r1 - (float)m[c]);
+        }
+        __bf16* out = reinterpret_cast<__bf16*>(planes);
+        *reinterpret_cast<bf16x4*>(out + e) = h;
+        *reinterpret_cast<bf16x4*>(out + (int64_t)N * K + e) = m;
+        *reinterpret_cast<bf16x4*>(out + 2 * (int64_t)N * K + e) = l;
     }
 }
 

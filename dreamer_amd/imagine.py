@@ -127,7 +127,8 @@ class ImagineEngine:
         returned as, buffers that live as long as the engine (overwritten by the next call with the
         same shape); every device address is then the same from call to call and the native side
         replays the block as one recorded hipGraph.  ``precision="bf16"``: the matrix products of the
-        large-row path take bf16 inputs (fp32 accumulation, everything else fp32)."""
+        large-row path take bf16 inputs (fp32 accumulation, everything else fp32).  ``precision="f32_split"``:
+        those products at fp32 accuracy on the bf16 matrix pipe (exact three-way split of both operands)."""
         d, dev = self.dims, self.device
         B, H = start.h.shape[0], int(horizon)
         if repack:
@@ -180,7 +181,7 @@ class ImagineEngine:
         io.gamma, io.lam = float(gamma), float(lam)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         io.use_graph = 1 if (persistent and forced_actions is None and forced_zidx is None) else 0
-        io.precision = {"f32": 0, "bf16": 1}[precision]
+        io.precision = {"f32": 0, "bf16": 1, "f32_split": 2}[precision]
         w = self._weights()
         N.check(N.lib().drm_imagine_block_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_imagine_block_f32")
         return out

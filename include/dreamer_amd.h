@@ -161,6 +161,11 @@ int drm_fused_linear_f32(const drm_linear_args* args, drm_stream_t stream);
  * rounded on load; v_mfma_f32_32x32x16_bf16).  No LayerNorm prologue (ln_gamma must be NULL); any M.
  * Results agree with the fp32 form to about 1e-2 relative (the bf16 tolerance of the rollout). */
 int drm_fused_linear_bf16(const drm_linear_args* args, drm_stream_t stream);
+/* The same product at fp32 accuracy on the bf16 matrix pipe: every fp32 operand is split exactly into three
+ * bf16 parts on load and the six leading partial products are accumulated in fp32 (the dropped ones are
+ * below the rounding of an fp32 product).  Results agree with drm_fused_linear_f32 to fp32 rounding
+ * (same nn.Linear semantics, lib/world_model.py:153-160).  No LayerNorm prologue; any M. */
+int drm_fused_linear_split(const drm_linear_args* args, drm_stream_t stream);
 
 /* ---- imagination block: lib/trainer.py:176-224 ----------------------------------------------
  * actor -> sample action -> WorldModel.step(prior) for H steps, then reward / continue heads,
@@ -242,7 +247,9 @@ typedef struct drm_imagine_io {
                                       graph afterwards (callers keep every buffer at a fixed address) */
     int32_t precision;             /* 0: fp32 everywhere.  1: the matrix products of the large-row path
                                       (B >= 256 or widths > 512) take bf16 inputs with fp32 accumulation;
-                                      LayerNorm, gates, sampling and the lambda-return stay fp32 */
+                                      LayerNorm, gates, sampling and the lambda-return stay fp32.
+                                      2: those products at fp32 accuracy from an exact three-way bf16 split
+                                      of both operands (see drm_fused_linear_split) */
 } drm_imagine_io;
 
 size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H);

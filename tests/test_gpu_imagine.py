@@ -126,6 +126,34 @@ def test_bf16_matrix_inputs_within_bf16_tolerance():
     assert worst > 1e-5   # the reduced-precision products really ran
 
 
+@pytest.mark.parametrize("B,H,D,M,L", [(300, 4, 128, 128, 8), (260, 2, 1024, 544, 6), (20, 2, 640, 1024, 6)])
+def test_split_products_meet_the_fp32_tolerance(B, H, D, M, L):
+    """Large-row path with the matrix products formed on the bf16 pipe from an exact three-way split of both
+    operands (six partial products, fp32 accumulation), teacher-forced along the oracle's trajectory: the
+    fp32 tolerance of the rollout holds, as it does for the fp32 MFMA form."""
+    d = dict(DIMS["small"], D=D, M=M, L=L, A=5)
+    salt = 900 + B
+    wm, actor, critic = build_models(d, salt)
+    ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    with torch.no_grad():
+        ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
+    ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
+    kw = dict(noise={"a": ea.to(DEV), "z": ez.to(DEV)}, forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV),
+              want_prior_logits=True)
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, precision="f32_split", **kw)
+    exact = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, **kw)
+    torch.cuda.synchronize()
+    differs = False
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+        assert rel_err(out[key].cpu(), ref[key]) < TOL, key
+        differs = differs or not torch.equal(out[key], exact[key])
+    assert differs   # the split kernels really ran (same values to rounding, not the same bits)
+
+
 def test_large_batch_properties():
     """B = 4096 trajectories (the large-batch case): rows are independent, so any slice of the batch
     must reproduce, bit for bit, what the same rows give when run alone."""

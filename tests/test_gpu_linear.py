@@ -77,3 +77,42 @@ def test_bf16_input_product_matches_rounded_reference(M, N, K):
     ref_f32 = (x.double() @ w.double().T + b.double()).float()
     assert float((y - ref_rounded).abs().max() / ref_rounded.abs().max()) < 2e-5
     assert float((y - ref_f32).abs().max() / ref_f32.abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 64), (4096, 512, 512), (1000, 1100, 1536), (37, 40, 96), (64, 128, 32)])
+def test_split_product_has_fp32_accuracy(M, N, K):
+    """fp32 product on the bf16 matrix pipe (exact three-way split of both operands, six partial products):
+    as close to the fp64 product as the fp32 MFMA form is, far below the bf16 tolerance."""
+    from dreamer_amd import _native as N_
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 3
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = (x.double() @ w.double().T + b.double())
+    y = N_.fused_linear(x.cuda(), w.cuda(), b.cuda(), split=True).cpu().double()
+    err_split = float((y - ref).abs().max() / ref.abs().max())
+    assert err_split < 2e-6 * np.sqrt(K / 64)
+    if M >= 256:    # rows the fp32 MFMA form of the same kernel family takes
+        y32 = N_.fused_linear(x.cuda(), w.cuda(), b.cuda()).cpu().double()
+        err_f32 = float((y32 - ref).abs().max() / ref.abs().max())
+        assert err_split < 4 * err_f32 + 1e-7
+
+
+def test_split_product_layout_and_table():
+    # X = I picks out columns of W: the split must reproduce fp32 values exactly (each is h + m + l)
+    K = 64
+    x = torch.eye(K)[:48]
+    w = (torch.arange(160 * K, dtype=torch.float32).reshape(160, K) * 1.000123 + 0.37)
+    y = N.fused_linear(x.to(DEV), w.to(DEV), split=True)
+    assert torch.equal(y.cpu(), w[:, :48].T.contiguous())
+    M, D, L, Kc, Nn = 150, 128, 8, 32, 96
+    xx = _t("x", (M, D))
+    w_full = _t("w", (Nn, D + L * Kc), 0.05)
+    b = _t("b", (Nn,), 0.1)
+    idx = torch.from_numpy((hash_uniform("i", (M, L), 5) * Kc).astype(np.int64))
+    z = F.one_hot(idx, Kc).float().reshape(M, L * Kc)
+    ref = (torch.cat([xx, z], -1).double() @ w_full.double().T + b.double()).float()
+    wd = w_full.to(DEV)
+    y = N.fused_linear(xx.to(DEV), wd[:, :D], b.to(DEV), table=w_full[:, D:].T.contiguous().to(DEV),
+                       zidx=idx.to(torch.uint8).to(DEV), split=True)
+    assert float((y.cpu() - ref).abs().max()) < 3e-6 * float(ref.abs().max())

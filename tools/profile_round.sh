@@ -35,5 +35,6 @@ pmc imagine4096 WRITE_SIZE --workload imagine4096 --steps 3 --warmup 1
 pmc imagine16 FETCH_SIZE --workload imagine16 --steps 10 --warmup 2
 pmc imagine16 WRITE_SIZE --workload imagine16 --steps 10 --warmup 2
 stats imagine4096_bf16 --workload imagine4096_bf16 --steps 20 --warmup 3
+stats imagine4096_split --workload imagine4096_split --steps 20 --warmup 3
 python3 "$root/tools/pmc_to_json.py" "$out" "$out/pmc.json"
 echo done
