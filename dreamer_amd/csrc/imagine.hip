@@ -682,7 +682,7 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
     // 64-column tiles when 128-column ones would give fewer than two workgroups per CU (fp32 form)
     int tiles128 = 0;
     for (int i = 0; i < np; ++i) tiles128 += (specs[i].N + BIG_BN - 1) / BIG_BN;
-    const bool narrow = precision == 0 && (int64_t)tiles128 * ((M + BIG_BM - 1) / BIG_BM) < 512 &&
+    const bool narrow = precision != 1 && (int64_t)tiles128 * ((M + BIG_BM - 1) / BIG_BM) < 512 &&
                         std::getenv("DRM_NO_NARROW_TILES") == nullptr;
     const int bn = narrow ? BIG_BN64 : BIG_BN;
     for (int i = 0; i < np; ++i) {
@@ -707,8 +707,10 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
     const dim3 grid(tiles, (M + BIG_BM - 1) / BIG_BM);
     if (precision == 1) k_linear_big_bf16<<<grid, dim3(256), 0, stream>>>(L);
-    else if (precision == 2 && presplit) k_linear_big_split<true><<<grid, dim3(256), 0, stream>>>(L);
-    else if (precision == 2) k_linear_big_split<false><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 2 && presplit && narrow) k_linear_big_split<true, 1><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 2 && presplit) k_linear_big_split<true, 2><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 2 && narrow) k_linear_big_split<false, 1><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 2) k_linear_big_split<false, 2><<<grid, dim3(256), 0, stream>>>(L);
     else if (narrow) k_linear_big64<<<grid, dim3(256), 0, stream>>>(L);
     else k_linear_big<<<grid, dim3(256), 0, stream>>>(L);
     DRM_LAUNCH_CHECK();

@@ -528,13 +528,16 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
 // operand, 46 KB), the next K-step's global loads in flight in registers during the MFMAs.
 // PRESPLIT: the weight operand comes from three bf16 images made once per call by k_split_planes (weights are
 // shared by every row tile and every step of a rollout), so only the activation operand is split here.
-template <bool PRESPLIT>
+// NT = 32-column accumulators per wave: 2 -> 64 x 128 tile, 1 -> 64 x 64 tile (launches whose 128-column grid would
+// put a single workgroup on a CU).
+template <bool PRESPLIT, int NT>
 __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
-    constexpr int A_PART = BIG_BM * BIG_LDH, B_PART = BIG_BN * BIG_LDH;
-    __shared__ __attribute__((aligned(16))) __bf16 smem_h[3 * A_PART + 3 * B_PART];      // 46,080 B >= 64 x 132 floats
-    static_assert(sizeof(__bf16) * (3 * A_PART + 3 * B_PART) >= sizeof(float) * BIG_BM * (BIG_BN + 4), "epilogue tile");
+    constexpr int BN = 64 * NT;
+    constexpr int A_PART = BIG_BM * BIG_LDH, B_PART = BN * BIG_LDH;
+    __shared__ __attribute__((aligned(16))) __bf16 smem_h[3 * A_PART + 3 * B_PART];      // NT = 2: 46,080 B
+    static_assert(sizeof(__bf16) * (3 * A_PART + 3 * B_PART) >= sizeof(float) * BIG_BM * (BN + 4), "epilogue tile");
     __bf16 (*sA)[BIG_BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BM][BIG_LDH]>(smem_h);
-    __bf16 (*sB)[BIG_BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BN][BIG_LDH]>(smem_h + 3 * A_PART);
+    __bf16 (*sB)[BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BN][BIG_LDH]>(smem_h + 3 * A_PART);
 
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
     int lin = blockIdx.y * nbx + blockIdx.x;
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     int pi = L.np - 1;
     while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
     const BigProblem& P = L.p[pi];
-    const int n0 = (bx - P.tile_begin) * BIG_BN;
+    const int n0 = (bx - P.tile_begin) * BN;
     const int m0 = by * BIG_BM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave & 1, wn = wave >> 1;
@@ -557,10 +560,10 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+    for (int i = 0; i < 2 * NT; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
 
-    // pre-split weights: 128 rows x 32 k x 3 images = 1536 16-byte pieces per K-step, six per thread:
-    // piece j of thread t is image j / 2, row t / 4 + 64 * (j % 2), k offset 8 * (t % 4)
+    // pre-split weights: BN rows x 32 k x 3 images = 12 BN 16-byte pieces per K-step, 3 NT per thread:
+    // thread t takes row t / 4 (and row t / 4 + 64 for NT = 2), k offset 8 * (t % 4), of each image
     const int prow = tid >> 2, pkq = (tid & 3) * 8;
     const uint16_t* ws0 = nullptr;
     const uint16_t* ws1 = nullptr;
@@ -582,16 +585,20 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     ra[1] = *reinterpret_cast<const float4*>(xa[1] + (ko));                 \
     if (PRESPLIT) {                                                         \
         rs0 = *reinterpret_cast<const u32x4*>(ws0 + (ko));                \
-        rs1 = *reinterpret_cast<const u32x4*>(ws1 + (ko));                \
         rs2 = *reinterpret_cast<const u32x4*>(ws0 + wplane + (ko));       \
-        rs3 = *reinterpret_cast<const u32x4*>(ws1 + wplane + (ko));       \
         rs4 = *reinterpret_cast<const u32x4*>(ws0 + 2 * wplane + (ko));   \
-        rs5 = *reinterpret_cast<const u32x4*>(ws1 + 2 * wplane + (ko));   \
+        if (NT == 2) {                                                      \
+            rs1 = *reinterpret_cast<const u32x4*>(ws1 + (ko));            \
+            rs3 = *reinterpret_cast<const u32x4*>(ws1 + wplane + (ko));   \
+            rs5 = *reinterpret_cast<const u32x4*>(ws1 + 2 * wplane + (ko)); \
+        }                                                                   \
     } else {                                                                \
         rb[0] = *reinterpret_cast<const float4*>(wb[0] + (ko));             \
         rb[1] = *reinterpret_cast<const float4*>(wb[1] + (ko));             \
-        rb[2] = *reinterpret_cast<const float4*>(wb[2] + (ko));             \
-        rb[3] = *reinterpret_cast<const float4*>(wb[3] + (ko));             \
+        if (NT == 2) {                                                      \
+            rb[2] = *reinterpret_cast<const float4*>(wb[2] + (ko));         \
+            rb[3] = *reinterpret_cast<const float4*>(wb[3] + (ko));         \
+        }                                                                   \
     }
 #define BIGS_PUT(S, row, v)                                                 \
     {                                                                       \
@@ -614,6 +621,9 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     BIGS_MMA(am, b0m, acc0) BIGS_MMA(am, b1m, acc1) BIGS_MMA(al, b0h, acc0) BIGS_MMA(al, b1h, acc1) \
     BIGS_MMA(ah, b0l, acc0) BIGS_MMA(ah, b1l, acc1) BIGS_MMA(am, b0h, acc0) BIGS_MMA(am, b1h, acc1) \
     BIGS_MMA(ah, b0m, acc0) BIGS_MMA(ah, b1m, acc1) BIGS_MMA(ah, b0h, acc0) BIGS_MMA(ah, b1h, acc1)
+#define BIGS_SIX(ah, am, al, b0h, b0m, b0l)                                 \
+    BIGS_MMA(am, b0m, acc0) BIGS_MMA(al, b0h, acc0) BIGS_MMA(ah, b0l, acc0) \
+    BIGS_MMA(am, b0h, acc0) BIGS_MMA(ah, b0m, acc0) BIGS_MMA(ah, b0h, acc0)
 
     BIGS_LOAD(0)
     f32x16 acc0, acc1;
@@ -626,16 +636,20 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
         BIGS_PUT(sA, srow + 32, ra[1])
         if (PRESPLIT) {
             *reinterpret_cast<u32x4*>(wdst) = rs0;
-            *reinterpret_cast<u32x4*>(wdst + 64 * BIG_LDH) = rs1;
             *reinterpret_cast<u32x4*>(wdst + B_PART) = rs2;
-            *reinterpret_cast<u32x4*>(wdst + B_PART + 64 * BIG_LDH) = rs3;
             *reinterpret_cast<u32x4*>(wdst + 2 * B_PART) = rs4;
-            *reinterpret_cast<u32x4*>(wdst + 2 * B_PART + 64 * BIG_LDH) = rs5;
+            if (NT == 2) {
+                *reinterpret_cast<u32x4*>(wdst + 64 * BIG_LDH) = rs1;
+                *reinterpret_cast<u32x4*>(wdst + B_PART + 64 * BIG_LDH) = rs3;
+                *reinterpret_cast<u32x4*>(wdst + 2 * B_PART + 64 * BIG_LDH) = rs5;
+            }
         } else {
             BIGS_PUT(sB, srow, rb[0])
             BIGS_PUT(sB, srow + 32, rb[1])
-            BIGS_PUT(sB, srow + 64, rb[2])
-            BIGS_PUT(sB, srow + 96, rb[3])
+            if (NT == 2) {
+                BIGS_PUT(sB, srow + 64, rb[2])
+                BIGS_PUT(sB, srow + 96, rb[3])
+            }
         }
         __syncthreads();
         if (ks + 1 < nk) { BIGS_LOAD((ks + 1) * BIG_BK) }
@@ -643,11 +657,15 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
         for (int half = 0; half < 2; ++half) {
             const bf16x8 ah = BIGS_FRAG(sA, 0, wm * 32 + li, half), am = BIGS_FRAG(sA, 1, wm * 32 + li, half),
                          al = BIGS_FRAG(sA, 2, wm * 32 + li, half);
-            const bf16x8 b0h = BIGS_FRAG(sB, 0, wn * 64 + li, half), b0m = BIGS_FRAG(sB, 1, wn * 64 + li, half),
-                         b0l = BIGS_FRAG(sB, 2, wn * 64 + li, half);
-            const bf16x8 b1h = BIGS_FRAG(sB, 0, wn * 64 + 32 + li, half), b1m = BIGS_FRAG(sB, 1, wn * 64 + 32 + li, half),
-                         b1l = BIGS_FRAG(sB, 2, wn * 64 + 32 + li, half);
-            BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)
+            const bf16x8 b0h = BIGS_FRAG(sB, 0, wn * 32 * NT + li, half), b0m = BIGS_FRAG(sB, 1, wn * 32 * NT + li, half),
+                         b0l = BIGS_FRAG(sB, 2, wn * 32 * NT + li, half);
+            if (NT == 2) {
+                const bf16x8 b1h = BIGS_FRAG(sB, 0, wn * 64 + 32 + li, half), b1m = BIGS_FRAG(sB, 1, wn * 64 + 32 + li, half),
+                             b1l = BIGS_FRAG(sB, 2, wn * 64 + 32 + li, half);
+                BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)
+            } else {
+                BIGS_SIX(ah, am, al, b0h, b0m, b0l)
+            }
         }
     }
 #undef BIGS_LOAD
@@ -655,17 +673,19 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 #undef BIGS_FRAG
 #undef BIGS_MMA
 #undef BIGS_TWELVE
+#undef BIGS_SIX
 
     // ---- epilogue (as k_linear_big): tile through LDS, + bias, + one-hot table rows, 16-byte stores
     __syncthreads();
-    float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem_h);
+    float (*sC)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem_h);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = acc0[i];
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
+        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 * NT + li] = acc0[i];
+        if (NT == 2) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
     }
     __syncthreads();
-    const int c4 = (tid & 31) * 4;
+    constexpr int TPR = BN / 4;                  // threads per output row
+    const int c4 = (tid % TPR) * 4;
     const int n = n0 + c4;
     if (n >= P.N) return;
     const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
@@ -676,7 +696,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
         if (n + 2 < P.N) bias.z = P.bias[n + 2];
         if (n + 3 < P.N) bias.w = P.bias[n + 3];
     }
-    for (int r = tid >> 5; r < BIG_BM; r += 8) {
+    for (int r = tid / TPR; r < BIG_BM; r += 256 / TPR) {
         const int m = m0 + r;
         if (m >= L.M) break;
         float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
