@@ -187,6 +187,33 @@ def test_large_batch_properties():
         assert rel_err(small[key].cpu(), got[key]) < TOL, key
 
 
+def test_large_batch_split_products_follow_the_fp32_form():
+    """B = 4096 x H = 15 at the default widths: the split products (both tile forms of the kernel run at this size,
+    64 x 128 and 64 x 64, with the weights read from their split images) along the fp32 form's own trajectory give
+    its states, heads and returns to the fp32 tolerance; 16 rows also against the oracle."""
+    d, salt, B, H = DIMS["default"], 6, 4096, 15
+    wm, actor, critic, eng = _engine(d, salt)
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt)).to(DEV)
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt)).to(DEV)
+    st = WorldModelState(h=h0.to(DEV), z=z0.to(DEV))
+    base = eng.run(st, H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False)
+    split = eng.run(st, H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False, precision="f32_split",
+                    forced_actions=base["actions"].contiguous(), forced_zidx=base["zidx"].contiguous())
+    torch.cuda.synchronize()
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns"):
+        assert rel_err(split[key].cpu(), base[key].cpu()) < TOL, key
+    assert not torch.equal(split["h"], base["h"])
+    sub = slice(2000, 2016)
+    with torch.no_grad():
+        ref = O.imagine_block(weights_of(wm), weights_of(actor), weights_of(critic), h0[sub], z0[sub],
+                              ea[:, sub].cpu(), ez[:, sub].cpu(), 0.997, 0.95)
+    if (torch.equal(base["zidx"][sub].cpu(), ref["z"].argmax(-1).to(torch.uint8))
+            and torch.equal(base["actions"][sub].cpu(), ref["actions"])):
+        for key in ("h", "rewards", "values", "lam_returns"):
+            assert rel_err(split[key][sub].cpu(), ref[key]) < TOL, key
+
+
 def test_graph_replay_equals_direct_launches():
     d, salt, B, H = DIMS["default"], 9, 16, 15
     wm, actor, critic, eng = _engine(d, salt)
