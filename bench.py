@@ -227,6 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="imagine16", choices=["imagine16", "imagine4096", "imagine4096_bf16", "imagine4096_split"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-kernels", action="store_true",
+                    help="skip the stand-alone bandwidth figures of the sampling / lambda-return / gather kernels")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--train-steps", type=int, default=20, help="full training updates to time as well (0 = skip)")
     ap.add_argument("--train-limit-s", type=float, default=420.0, help="give up on the training updates after this long")
@@ -338,6 +340,19 @@ def main():
                         kernels={k: {"us_per_step": v["ms_net"] * 1e3 / args.profile_steps,
                                      "launches_per_step": v["launches"] / args.profile_steps} for k, v in summ.items()})
 
+    # the three HBM-bound kernels of the path at device-filling sizes (they are single 6-us launches inside the
+    # block above): achieved GB/s against the 8 TB/s peak, algorithmic bytes / event-timed launch
+    stream_kernels = None
+    if rank == 0 and world == 1 and not args.no_stream_kernels:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_stream
+            stream_kernels = {"peak_GB/s": bench_stream.PEAK_GBS,
+                              "rows": bench_stream.run(large_only=True, device=str(device), verbose=False)}
+        except Exception as e:
+            stream_kernels = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
     def emit(train):
         if rank != 0:
             return
@@ -353,6 +368,7 @@ def main():
                        "B_per_gpu": B, "H": H},
             "algorithmic_tflops": value * FLOP_PER_LATENT_STEP / 1e12,
             "roofline": roofline,
+            "stream_kernels": stream_kernels,
             "train": train,
         }
         if not args.no_cpu_baseline and world == 1:

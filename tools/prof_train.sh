@@ -9,7 +9,7 @@ cd /tmp
 export TMPDIR=/tmp
 export DRM_BENCH_NO_ACTING=1   # the window at the end of the trace must hold training updates only
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$out" -o "$name" --output-format csv -- \
-    python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 --profile-steps 0 --train-steps 30 > "$out/bench.json" 2> "$out/err.txt"
+    python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --steps 2 --warmup 1 --profile-steps 0 --train-steps 30 > "$out/bench.json" 2> "$out/err.txt"
 python3 "$root/tools/prof_window.py" "$out" 0.02 110 > "$out/stats.txt"
 find "$out" -name '*kernel_trace.csv' -delete
 cat "$out/stats.txt"
