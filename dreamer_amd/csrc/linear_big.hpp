@@ -771,14 +771,23 @@ __global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ 
     const int row = blockIdx.x * 4 + wave;
     if (row >= M) return;
     const float* x = X + (int64_t)row * ldx;
-    float4 v[NV];
+    float4 v[NV], gg[NV], ee[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int k = (i * 64 + lane) * 4;
         v[i] = k < K ? *reinterpret_cast<const float4*>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
+    if (NV <= 4) {   // scale and shift fetched beside the row, not after the two reductions
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = min((i * 64 + lane) * 4, K - 4);
+            gg[i] = *reinterpret_cast<const float4*>(g + k);
+            ee[i] = *reinterpret_cast<const float4*>(e + k);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = group_sum<64>(s) / (float)K;
     float q = 0.f;
 #pragma unroll
@@ -794,13 +803,15 @@ __global__ __launch_bounds__(256) void k_ln_silu_rows(const float* __restrict__ 
     for (int i = 0; i < NV; ++i) {
         const int k = (i * 64 + lane) * 4;
         if (k < K) {
-            const float4 gg = *reinterpret_cast<const float4*>(g + k);
-            const float4 ee = *reinterpret_cast<const float4*>(e + k);
+            if (NV > 4) {
+                gg[i] = *reinterpret_cast<const float4*>(g + k);
+                ee[i] = *reinterpret_cast<const float4*>(e + k);
+            }
             float4 o;
-            o.x = silu_f((v[i].x - mean) * rstd * gg.x + ee.x);
-            o.y = silu_f((v[i].y - mean) * rstd * gg.y + ee.y);
-            o.z = silu_f((v[i].z - mean) * rstd * gg.z + ee.z);
-            o.w = silu_f((v[i].w - mean) * rstd * gg.w + ee.w);
+            o.x = silu_f((v[i].x - mean) * rstd * gg[i].x + ee[i].x);
+            o.y = silu_f((v[i].y - mean) * rstd * gg[i].y + ee[i].y);
+            o.z = silu_f((v[i].z - mean) * rstd * gg[i].z + ee[i].z);
+            o.w = silu_f((v[i].w - mean) * rstd * gg[i].w + ee[i].w);
             *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + k) = o;
         }
     }
