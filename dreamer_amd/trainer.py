@@ -44,7 +44,7 @@ def _adam(params, lr, eps, capturable=False):
 
 
 @contextlib.contextmanager
-def _recording(graph):
+def _recording(graph, stream=None):
     """torch.cuda.graph(graph) with the cyclic garbage collector held off: a collection that runs while
     the stream is recording may free pinned memory, streams or other graphs, calls the runtime refuses
     during a recording (the process then aborts in a destructor)."""
@@ -52,7 +52,7 @@ def _recording(graph):
     gc.collect()
     gc.disable()
     try:
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=stream):
             yield
     finally:
         if was_enabled:
@@ -99,7 +99,11 @@ class _GraphedUpdate:
         # the parameters' gradient-accumulation nodes were made on the main stream by the eager updates;
         # autograd notes the change of stream once per node, which is expected here
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
-        side = torch.cuda.Stream()
+        # a caller that runs its updates on a stream of its own gets the recording on that same stream: autograd's
+        # gradient-accumulation nodes then belong to the recording stream and the graph stays one chain
+        own = torch.cuda.current_stream() != torch.cuda.default_stream()
+        side = torch.cuda.current_stream() if own else torch.cuda.Stream()
+        self._capture_stream = side if own else None
         side.wait_stream(torch.cuda.current_stream())
         rng = torch.cuda.get_rng_state()
         with torch.cuda.stream(side):   # settle allocator / autograd state on a side stream: loss + backward only
@@ -113,7 +117,7 @@ class _GraphedUpdate:
         dot = os.environ.get("DRM_GRAPH_DOT")           # diagnostic: node list of the recorded update as a DOT file
         if dot:
             self.g_loss.enable_debug_mode()
-        with _recording(self.g_loss):
+        with _recording(self.g_loss, self._capture_stream):
             self.grads.zero()
             self.loss_out = self.loss_fn(*self.static)
             self.loss_out.backward()
@@ -123,7 +127,7 @@ class _GraphedUpdate:
 
     def _capture_step(self, params) -> None:
         self.g_step = torch.cuda.CUDAGraph()
-        with _recording(self.g_step):
+        with _recording(self.g_step, getattr(self, "_capture_stream", None)):
             _clip_and_step(self.optim, params, self.clip)
             if self.post is not None:
                 self.post()
