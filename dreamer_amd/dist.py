@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -72,6 +74,8 @@ class FlatGrads:
         self.params: List[torch.nn.Parameter] = []
         self.offsets: List[int] = []
         self.static = False
+        self.channels_last_kernels = os.environ.get("DRM_TOWER_CHANNELS_LAST", "0") == "1" and any(
+            p.is_cuda for p in module.parameters())
         if static:
             self._build_static()
 
@@ -104,11 +108,19 @@ class FlatGrads:
             o += (p.numel() + 63) // 64 * 64
         self.flat = torch.zeros(o, dtype=ref.dtype, device=ref.device)
         self.flat_params = torch.zeros(o, dtype=ref.dtype, device=ref.device)
-        self.views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)]
+
+        def slot(buf, p, off):
+            # convolution kernels keep their logical (O, I, kh, kw) shape; with channels-last towers their slot is laid
+            # out (O, kh, kw, I), the format the convolution backend then takes without transposing them on every call
+            if p.dim() == 4 and self.channels_last_kernels:
+                return buf[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+            return buf[off:off + p.numel()].view_as(p)
+
+        self.views = [slot(self.flat, p, off) for p, off in zip(self.params, self.offsets)]
         self._missing = None
         with torch.no_grad():
             for p, off in zip(self.params, self.offsets):
-                pv = self.flat_params[off:off + p.numel()].view_as(p)
+                pv = slot(self.flat_params, p, off)
                 pv.copy_(p.data)
                 p.data = pv
 

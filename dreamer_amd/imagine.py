@@ -45,7 +45,11 @@ class ImagineEngine:
         self.dims = N.drm_dims(D=wm.hidden_size, L=wm.num_latents, K=wm.classes_per_latent,
                                M=wm.dyn.mlp[0].out_features, A=wm.action_size, E=wm.seq.a_emb.embedding_dim,
                                NB=critic.num_buckets, unimix_eps=wm.unimix_eps)
+        # the rollout reads vectors and matrices; the convolution kernels of the towers (4-D, possibly kept in the
+        # channels-last format) are not part of it
         for m in list(wm.parameters()) + list(actor.parameters()) + list(critic.parameters()):
+            if m.dim() == 4:
+                continue
             if m.dtype != torch.float32 or not m.is_contiguous():
                 raise N.NativeError("parameters must be contiguous fp32")
         nbytes = N.lib().drm_pack_imagine_bytes(C.byref(self.dims))
