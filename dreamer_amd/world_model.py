@@ -493,4 +493,4 @@ class WorldModel(nn.Module):
             rep = self._representation_loss(postf, prior).mean()
         total = self.beta_pred * pred + self.beta_dyn * dyn + self.beta_rep * rep
         return total, {"total_loss": total, "pred_loss": pred, "dyn_loss": dyn, "rep_loss": rep, "state": last,
-                       "h": h, "post_logits": post, "prior_logits": prior.view(B, T, L, K)}
+                       "h": h, "z": z, "post_logits": post, "prior_logits": prior.view(B, T, L, K)}

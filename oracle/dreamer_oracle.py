@@ -255,21 +255,30 @@ def lambda_return(R: Tensor, C: Tensor, V: Tensor, V_last: Tensor, gamma: float,
 
 def imagine_block(ww: Weights, wa: Weights, wc: Weights, h0: Tensor, z0: Tensor,
                   expo_a: Tensor, expo_z: Tensor, gamma: float, lam: float, eps: float = 0.01,
-                  run_decoder: bool = False, forced_actions: Optional[Tensor] = None):
+                  run_decoder: bool = False, forced_actions: Optional[Tensor] = None,
+                  forced_zidx: Optional[Tensor] = None):
     """The no-grad imagination block, lib/trainer.py:176-224.
 
     expo_a: (H, B, A) and expo_z: (H, B, L, K) Exp(1) draws, consumed per step in the order
-    [action, z].  ``forced_actions`` (B, H) teacher-forces the sampled actions.
+    [action, z].  ``forced_actions`` (B, H) teacher-forces the sampled actions, ``forced_zidx`` (B, H, L) the
+    sampled latent classes (the heads then see the forced latent; what the sampler drew from each step's own
+    logits is returned as ``actions_sampled`` / ``zidx_sampled``).
     """
     H = expo_z.size(0)
     h, z = h0, z0
-    hs, zs, acts, rews, conts, logps, priors = [], [], [], [], [], [], []
+    hs, zs, acts, rews, conts, logps, priors, drawn_a, drawn_z = [], [], [], [], [], [], [], [], []
     for t in range(H):
         logp = actor_log_probs(wa, h, z, eps)
         a = sample_action(logp, expo_a[t])
+        drawn_a.append(a)
         if forced_actions is not None:
             a = forced_actions[:, t]
         h, z, info = prior_step(ww, h, z, a, expo_z[t], eps, run_decoder)
+        drawn_z.append(info["idx"])
+        if forced_zidx is not None:
+            z = F.one_hot(forced_zidx[:, t].long(), z.size(-1)).to(h.dtype)
+            info["r_hat"] = scalar_head(ww, "rew.", h, z)
+            info["c_hat"] = scalar_head(ww, "cont.", h, z)
         hs.append(h); zs.append(z); acts.append(a); logps.append(logp); priors.append(info["prior_logits"])
         rews.append(symexp(info["r_hat"].squeeze(-1)))
         conts.append(torch.sigmoid(info["c_hat"].squeeze(-1)))
@@ -279,7 +288,8 @@ def imagine_block(ww: Weights, wa: Weights, wc: Weights, h0: Tensor, z0: Tensor,
     V_last = critic_value(wc, hs[-1], zs[-1])
     ret = lambda_return(R, C, V, V_last, gamma, lam)
     return {"h": Hh, "z": Hz, "actions": A, "rewards": R, "conts": C, "values": V, "v_last": V_last,
-            "lam_returns": ret, "actor_logp": torch.stack(logps, 1), "prior_logits": torch.stack(priors, 1)}
+            "lam_returns": ret, "actor_logp": torch.stack(logps, 1), "prior_logits": torch.stack(priors, 1),
+            "actions_sampled": torch.stack(drawn_a, 1), "zidx_sampled": torch.stack(drawn_z, 1)}
 
 
 # --------------------------------------------------------------------------- world-model loss

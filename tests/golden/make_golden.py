@@ -48,13 +48,36 @@ def _install_stubs():
         sys.modules.setdefault(name, mod)
 
 
+REFERENCE = "/root/reference"
+
+
+def _bind_reference_lib():
+    """Make ``lib`` mean the reference's package, whatever else is importable under that name.
+
+    The reference's ``lib/`` has no ``__init__.py`` (a namespace package); this repository ships a regular
+    package of the same name that aliases ``dreamer_amd``, and regular packages win over namespace packages
+    regardless of ``sys.path`` order.  So the name is bound explicitly: a module object whose ``__path__`` holds
+    only the reference's directory, registered before anything imports ``lib.*``."""
+    for name in [n for n in sys.modules if n == "lib" or n.startswith("lib.")]:
+        del sys.modules[name]
+    pkg = types.ModuleType("lib")
+    pkg.__path__ = [os.path.join(REFERENCE, "lib")]
+    pkg.__package__ = "lib"
+    sys.modules["lib"] = pkg
+
+
 _install_stubs()
-sys.path.insert(0, "/root/reference")
+_bind_reference_lib()
 from lib.actor import Actor  # noqa: E402
 from lib.critic import Critic  # noqa: E402
 from lib.replay_buffer import ReplayBuffer  # noqa: E402
 from lib.utils import log_unimix, symexp, symlog  # noqa: E402
 from lib.world_model import WorldModel, WorldModelState  # noqa: E402
+
+for _cls in (Actor, Critic, ReplayBuffer, WorldModel):
+    _file = sys.modules[_cls.__module__].__file__
+    assert _file.startswith(REFERENCE + os.sep), f"{_cls.__name__} was imported from {_file}, not from the reference"
+assert sys.modules[log_unimix.__module__].__file__.startswith(REFERENCE + os.sep)
 
 # ----------------------------------------------------------------------------- noise injection
 _ORIG_EXPONENTIAL = torch.Tensor.exponential_
@@ -188,10 +211,16 @@ def golden_imagine(tag, out_dir, salt, min_margin=None):
     return True
 
 
-def golden_observe(tag, out_dir, salt):
+def golden_observe(tag, out_dir, salt, B=None, T=None, name=None, compact=False, min_margin=None):
+    """World-model loss + backward over a (B, T) batch.  ``compact``: outputs only (losses, last state, every sampled
+    index, the recurrent state every 8th step, gradient norms and slices) for the full-size batches, whose
+    per-step tensors would be tens of MB."""
     d = DIMS[tag]
     wm, _, _ = build_models(d, salt)
-    B, T, L, K, A = (d["B"] if tag == "small" else 2), d["T"], d["L"], d["K"], d["A"]
+    B = B if B is not None else (d["B"] if tag == "small" else 2)
+    T = T if T is not None else d["T"]
+    L, K, A = d["L"], d["K"], d["A"]
+    name = name or f"observe_{tag}"
     obs_u8 = (hash_uniform("obs", (B, T, *d["obs_shape"]), salt) * 256).astype(np.uint8)
     actions = (hash_uniform("act", (B, T), salt) * A).astype(np.int64)
     rewards = ((hash_uniform("rew", (B, T), salt) - 0.5) * 4).astype(np.float32)
@@ -216,14 +245,27 @@ def golden_observe(tag, out_dir, salt):
     wm.step = traced_step
     loss, info = wm.loss(obs, torch.from_numpy(actions), torch.from_numpy(rewards), torch.from_numpy(continues))
     assert not _QUEUE
+    # margin of every posterior draw (the reset draws are argmin(E): exact on any hardware)
+    post = torch.stack(trace["post"], 1)
+    lp = log_unimix(post, 0.01) - torch.log(e_z.permute(1, 0, 2, 3))
+    top2 = lp.topk(2, dim=-1).values
+    margin = float((top2[..., 0] - top2[..., 1]).min())
+    print(f"{name} salt {salt}: min z margin {margin:.3e}")
+    if min_margin is not None and margin < min_margin:
+        return False
     wm.zero_grad()
     loss.backward()
-    out = dict(salt=salt, B=B, total=loss.detach().numpy(), pred=info["pred_loss"].detach().numpy(),
+    out = dict(salt=salt, B=B, T=T, total=loss.detach().numpy(), pred=info["pred_loss"].detach().numpy(),
                dyn=info["dyn_loss"].detach().numpy(), rep=info["rep_loss"].detach().numpy(),
-               h=torch.stack(trace["h"], 1).numpy(), post_logits=torch.stack(trace["post"], 1).numpy(),
-               prior_logits=torch.stack(trace["prior"], 1).numpy(),
                zidx=torch.stack(trace["idx"], 1).numpy().astype(np.uint8),
-               h_last=info["state"].h.detach().numpy())
+               h_last=info["state"].h.detach().numpy(), z_margin=np.float64(margin))
+    if compact:
+        out.update(h_every8=torch.stack(trace["h"], 1)[:, 7::8].numpy(), post_last=post[:, -1].numpy(),
+                   prior_last=trace["prior"][-1].numpy())
+    else:
+        out.update(h=torch.stack(trace["h"], 1).numpy(), post_logits=post.numpy(),
+                   prior_logits=torch.stack(trace["prior"], 1).numpy())
+        del out["T"], out["z_margin"]      # the first fixtures were written without them
     gn = {}
     for k, p in wm.named_parameters():
         gn[k] = float(p.grad.double().norm()) if p.grad is not None else -1.0  # fp64: an fp32 sum over 1e7 squares drifts
@@ -232,8 +274,9 @@ def golden_observe(tag, out_dir, salt):
     for k in ("seq.gru.weight_hh", "seq.linear.weight", "enc.fc.0.weight", "dyn.head.bias", "seq.a_emb.weight"):
         g = dict(wm.named_parameters())[k].grad
         out["grad:" + k] = g.reshape(-1)[:256].numpy().copy()
-    np.savez_compressed(os.path.join(out_dir, f"observe_{tag}.npz"), **out)
-    print(f"observe_{tag}: total {float(loss):.6f}")
+    np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
+    print(f"{name}: total {float(loss.detach()):.6f}")
+    return True
 
 
 def golden_replay(out_dir):
@@ -334,6 +377,11 @@ def main():
     while not golden_imagine("default", args.out, salt=salt, min_margin=1.5e-4):
         salt += 1
     golden_observe("default", args.out, salt=21)
+    # the per-GPU training batch (16 sequences x 64 steps, lib/config.py:18-19) and the 50-step variant, default
+    # sizes, outputs only; the first salt whose smallest posterior-draw margin is clear of fp32 noise
+    for name, T, salt in (("observe_full", 64, 31), ("observe_t50", 50, 41)):
+        while not golden_observe("default", args.out, salt=salt, B=16, T=T, name=name, compact=True, min_margin=1.0e-4):
+            salt += 1
 
 
 if __name__ == "__main__":

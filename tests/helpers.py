@@ -56,8 +56,8 @@ def expo(name, shape, salt=0):
     return torch.from_numpy(hash_exponential(name, shape, salt))
 
 
-def observe_inputs(d, salt, B):
-    T, L, K, A = d["T"], d["L"], d["K"], d["A"]
+def observe_inputs(d, salt, B, T=None):
+    T, L, K, A = (T or d["T"]), d["L"], d["K"], d["A"]
     obs_u8 = (hash_uniform("obs", (B, T, *d["obs_shape"]), salt) * 256).astype(np.uint8)
     actions = (hash_uniform("act", (B, T), salt) * A).astype(np.int64)
     rewards = ((hash_uniform("rew", (B, T), salt) - 0.5) * 4).astype(np.float32)
@@ -69,6 +69,23 @@ def observe_inputs(d, salt, B):
 
 
 def rel_err(a, b):
+    """Norm-wise error: largest absolute difference over the largest reference magnitude.  Entries much smaller
+    than the tensor's largest are only loosely bound by it; ``assert_close_elementwise`` is the per-entry check."""
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close_elementwise(a, b, rtol=1e-5, atol_scale=1e-6, what=""):
+    """Every entry: |a - b| <= rtol * |b| + atol_scale * (root-mean-square of b).  The absolute term is the
+    rounding floor of an fp32 sum whose terms have the tensor's typical magnitude (an entry that is a near-cancelling
+    sum of O(rms) terms cannot be reproduced to a fraction of itself); it is 10 x smaller than the norm-wise bound
+    relative to the rms and far smaller relative to the max."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = float(b.pow(2).mean().sqrt().clamp_min(1e-30))
+    excess = (a - b).abs() - (rtol * b.abs() + atol_scale * scale)
+    worst = int(excess.argmax())
+    assert float(excess.max()) <= 0.0, (what, "entry", worst, float(a.reshape(-1)[worst]), float(b.reshape(-1)[worst]),
+                                         "rms", scale)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import DIMS, build_models, load, observe_inputs, rel_err
+from helpers import DIMS, assert_close_elementwise, build_models, load, observe_inputs, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -34,6 +34,42 @@ def test_world_model_loss_and_grads_match_reference(tag):
             assert grad is None, name
         else:
             assert abs(float(grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-3), (name, float(grad.double().norm()), ref)
+    for key in g.files:
+        if key.startswith("grad:"):
+            assert rel_err(params[key[5:]].grad.reshape(-1)[:256].cpu(), g[key]) < 2e-4, key
+
+
+@pytest.mark.parametrize("name", ["observe_full", "observe_t50"])
+def test_full_size_batches_match_reference(name):
+    """The per-GPU training batch at default sizes (16 sequences x 64 steps, lib/config.py:18-19) and the 50-step
+    variant through ``WorldModel.loss`` + backward: every sampled index, the recurrent states, the three loss terms
+    and every parameter's gradient norm against the reference's."""
+    g = load(f"{name}.npz")
+    d, salt, B, T = DIMS["default"], int(g["salt"]), int(g["B"]), int(g["T"])
+    wm, _, _ = build_models(d, salt)
+    wm = wm.to(DEV)
+    obs, actions, rewards, continues, noise = observe_inputs(d, salt, B, T)
+    noise = {k: v.to(DEV) for k, v in noise.items()}
+    total, info = wm.loss(obs.to(DEV).float() / 255.0, actions.to(DEV), rewards.to(DEV), continues.to(DEV), noise=noise)
+    assert np.array_equal(info["z"].detach().argmax(-1).cpu().numpy().astype(np.uint8), g["zidx"])
+    assert np.array_equal(info["state"].z.detach().argmax(-1).cpu().numpy().astype(np.uint8), g["zidx"][:, -1])
+    h = info["h"].detach().cpu()
+    assert rel_err(h[:, 7::8], g["h_every8"]) < TOL
+    assert_close_elementwise(h[:, 7::8], g["h_every8"], rtol=1e-5, atol_scale=2e-6, what="h")
+    assert rel_err(info["state"].h.detach().cpu(), g["h_last"]) < TOL
+    assert rel_err(info["post_logits"].detach()[:, -1].cpu(), g["post_last"]) < TOL
+    assert rel_err(info["prior_logits"].detach()[:, -1].cpu(), g["prior_last"]) < TOL
+    assert rel_err(total.detach().cpu(), g["total"]) < TOL
+    for key in ("pred", "dyn", "rep"):
+        assert rel_err(info[key + "_loss"].detach().cpu(), g[key]) < TOL, key
+    total.backward()
+    params = dict(wm.named_parameters())
+    for pname, ref in zip(g["grad_names"], g["grad_norms"]):
+        grad = params[str(pname)].grad
+        if ref < 0:
+            assert grad is None, pname
+        else:
+            assert abs(float(grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-3), (pname, float(grad.double().norm()), ref)
     for key in g.files:
         if key.startswith("grad:"):
             assert rel_err(params[key[5:]].grad.reshape(-1)[:256].cpu(), g[key]) < 2e-4, key

@@ -1,4 +1,6 @@
 """The CPU oracle against the golden vectors captured from the reference (CPU only)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,3 +121,49 @@ def test_observe_loss_and_grads(tag):
         if key.startswith("grad:"):
             got = w[key[5:]].grad.reshape(-1)[:256]
             assert rel_err(got, g[key]) < 1e-4, key
+
+
+@pytest.mark.parametrize("name", ["observe_full", "observe_t50"])
+def test_observe_full_size_batches(name):
+    """The per-GPU training batch at default sizes (16 sequences x 64 steps) and the 50-step variant: losses, every
+    sampled index, recurrent states and gradient norms of the reference."""
+    g = load(f"{name}.npz")
+    d, salt, B, T = DIMS["default"], int(g["salt"]), int(g["B"]), int(g["T"])
+    wm, _, _ = build_models(d, salt)
+    w = {k: v.requires_grad_(v.is_floating_point()) for k, v in weights_of(wm).items()}
+    obs, actions, rewards, continues, noise = observe_inputs(d, salt, B, T)
+    total, info = O.wm_loss(w, obs.float() / 255.0, actions, rewards, continues, noise["init"], noise["reset"], noise["z"])
+    assert np.array_equal(info["idx"].numpy().astype(np.uint8), g["zidx"])
+    assert rel_err(info["h"].detach()[:, 7::8], g["h_every8"]) < TOL
+    assert rel_err(info["h_last"].detach(), g["h_last"]) < TOL
+    assert rel_err(info["post_logits"].detach()[:, -1], g["post_last"]) < TOL
+    assert rel_err(info["prior_logits"].detach().reshape(B, T, d["L"], d["K"])[:, -1], g["prior_last"]) < TOL
+    assert rel_err(total.detach(), g["total"]) < TOL
+    for key in ("pred", "dyn", "rep"):
+        assert rel_err(info[key + "_loss"].detach(), g[key]) < TOL, key
+    total.backward()
+    for name_, ref in zip(g["grad_names"], g["grad_norms"]):
+        grad = w[str(name_)].grad
+        if ref < 0:
+            assert grad is None or float(grad.abs().max()) == 0.0, name_
+        else:
+            assert abs(float(grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-3), (name_, float(grad.double().norm()), ref)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib"), reason="the reference tree exists only in the build container")
+def test_recipe_imports_the_reference_and_reproduces_a_fixture(tmp_path):
+    """tests/golden/make_golden.py, run as committed, must bind ``lib`` to the reference's package (not to this
+    repository's alias package of the same name) and regenerate a committed fixture bit for bit."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.argv=['make_golden']; sys.path.insert(0, %r); import make_golden as mg; "
+            "assert sys.modules['lib.world_model'].__file__.startswith('/root/reference/'); "
+            "mg.golden_observe('small', %r, salt=11); mg.golden_imagine('small', %r, salt=11)"
+            % (os.path.join(here, "golden"), str(tmp_path), str(tmp_path)))
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=os.path.dirname(here), timeout=600)
+    for f in ("observe_small.npz", "imagine_small.npz"):
+        new, old = np.load(tmp_path / f), load(f)
+        assert sorted(new.files) == sorted(old.files)
+        for k in old.files:
+            assert np.array_equal(new[k], old[k]), (f, k)
