@@ -65,19 +65,26 @@ def start_states(B, cfg, device, seed=1):
 
 # kernels (rocprofv3 names) behind each timing class of the library
 CLASS_KERNELS = {"linear": ("k_skinny", "k_linear16<1, 0", "k_linear16m"), "k_linear_big": ("k_linear_big",)}
+MFMA_CLASSES = ("k_linear_big",)   # classes whose launches take the precision of the block
 
 
 def pmc_traffic(workload, cls):
     """HBM-side bytes per launch of a kernel class from the committed rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 16-byte-per-lane reads at half their
-    size on gfx950 and is doubled).  None when no pass of this workload is on file."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc.json")
-    if not os.path.exists(path) or cls not in CLASS_KERNELS:
-        return None
+    size on gfx950 and is doubled), and the file they were read from.  (None, None) when no pass of this
+    workload is on file."""
+    for rel in ("profiles/r2_pmc.json", "profiles/r1_pmc.json"):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
+    if cls not in CLASS_KERNELS:
+        return None, None
     try:
         table = json.load(open(path)).get(workload, {})
     except (OSError, ValueError):
-        return None
+        return None, None
     tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     n = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
     for kernel, ctrs in table.items():
@@ -88,8 +95,9 @@ def pmc_traffic(workload, cls):
                 tot[c] += ctrs[c]["total"]
                 n[c] += ctrs[c]["dispatches"]
     if n["FETCH_SIZE"] == 0 or n["WRITE_SIZE"] == 0:
-        return None
-    return 1024.0 * (2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"])
+        return None, None
+    return (1024.0 * (2.0 * tot["FETCH_SIZE"] / n["FETCH_SIZE"] + tot["WRITE_SIZE"] / n["WRITE_SIZE"]),
+            rel + " (committed rocprofv3 --pmc passes of this workload, not collected in this run)")
 
 
 def cpu_baseline(cfg, wm, actor, critic, B, H, budget_s=15.0):
@@ -169,8 +177,26 @@ def measure_train(device, world, rank, steps, warmup, fence):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ups = steps / dt
+    collective = None
+    if world > 1:
+        # the gradient all-reduce on its own: the world model's flat buffer, ten calls, device-timed on this rank
+        flat = learner.g_wm.flat
+        from dreamer_amd import dist as DD
+        for _ in range(3):
+            DD.all_reduce_sum(flat)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            DD.all_reduce_sum(flat)
+        fence()
+        ar = (time.perf_counter() - t1) / 10
+        nbytes = flat.numel() * 4
+        collective = {"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""), "ranks": dist.get_world_size(),
+                      "world_model_allreduce_bytes": nbytes, "world_model_allreduce_ms": ar * 1e3,
+                      "algbw_GB/s": nbytes / ar / 1e9, "busbw_GB/s": nbytes / ar / 1e9 * 2 * (world - 1) / world}
+        progress(f"all-reduce of {nbytes / 1e6:.1f} MB over {world} ranks ({collective['backend']}): {ar * 1e3:.3f} ms")
     acting = None if os.environ.get("DRM_BENCH_NO_ACTING", "0") == "1" else measure_acting(learner, device, rng)
-    return {"acting": acting, "host_ms_per_update": host_dt / steps * 1e3, "updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
+    return {"acting": acting, "collective": collective, "host_ms_per_update": host_dt / steps * 1e3, "updates_per_sec": ups, "ms_per_update": dt / steps * 1e3, "n_gpus": world, "per_gpu_batch": "16 x 64",
             "replayed_steps_per_sec": ups * world * cfg.batch_size * cfg.batch_length, "steps": steps, "warmup": warmup,
             "grad_allreduce_bytes_per_update": 4 * sum(g.flat.numel() for g in (learner.g_wm, learner.g_actor, learner.g_critic))}
 
@@ -230,6 +256,8 @@ def main():
     ap.add_argument("--no-stream-kernels", action="store_true",
                     help="skip the stand-alone bandwidth figures of the sampling / lambda-return / gather kernels")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the large-batch (B = 4096) and the rebuilt-tables measurements beside the default workload")
     ap.add_argument("--train-steps", type=int, default=20, help="full training updates to time as well (0 = skip)")
     ap.add_argument("--train-limit-s", type=float, default=420.0, help="give up on the training updates after this long")
     args = ap.parse_args()
@@ -257,19 +285,9 @@ def main():
     from dreamer_amd.world_model import WorldModelState
 
     N.check(N.lib().drm_arch_ok(), "drm_arch_ok")
-    B = 16 if args.workload == "imagine16" else 4096
-    precision = "bf16" if args.workload.endswith("_bf16") else "f32_split" if args.workload.endswith("_split") else "f32"
     cfg, wm, actor, critic = build_models(device)
     H = cfg.imagination_horizon
     eng = ImagineEngine(wm, actor, critic)
-    h0, z0 = start_states(B, cfg, device, seed=1 + rank)
-    start = WorldModelState(h=h0, z=z0)
-    zidx0 = N.onehot_to_index(z0)
-    A, L, K = wm.action_size, cfg.num_latents, cfg.classes_per_latent
-
-    def step():
-        # draws the Exp(1) noise of the block (two generator calls) and runs the block
-        return eng.run(start, H, cfg.gamma, cfg.lam, start_zidx=zidx0, repack=False, persistent=True, precision=precision)
 
     def fence():
         torch.cuda.synchronize()
@@ -277,24 +295,42 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out["lam_returns"]).all()
-    progress(f"imagination block: {elapsed / args.steps * 1e3:.3f} ms per block on this rank")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure_imagine(workload, steps, warmup, profile_steps, repack=False):
+        """Times `steps` imagination blocks of one workload (after `warmup` untimed ones, barrier + device
+        synchronisation on both sides, maximum over ranks) and, on rank 0, the per-kernel-class launch durations of
+        a short separate pass with HIP events on the launch stream.  `repack`: the one-hot gather tables are rebuilt
+        from the weights before every block, as a training update must after its optimiser step."""
+        B = 16 if workload == "imagine16" else 4096
+        precision = "bf16" if workload.endswith("_bf16") else "f32_split" if workload.endswith("_split") else "f32"
+        h0, z0 = start_states(B, cfg, device, seed=1 + rank)
+        start = WorldModelState(h=h0, z=z0)
+        zidx0 = N.onehot_to_index(z0)
 
-    # per-kernel timing with HIP events on the launch stream, in a separate short pass
-    roofline = None
-    if rank == 0 and args.profile_steps > 0:
+        def step():
+            # draws the Exp(1) noise of the block (one generator call for both tensors) and runs the block
+            return eng.run(start, H, cfg.gamma, cfg.lam, start_zidx=zidx0, repack=repack, persistent=True, precision=precision)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert torch.isfinite(out["lam_returns"]).all()
+        progress(f"{workload}{' (tables rebuilt per block)' if repack else ''}: {elapsed / steps * 1e3:.3f} ms per block on this rank")
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        res = {"B": B, "precision": precision, "elapsed": elapsed, "steps": steps, "warmup": warmup,
+               "ms_per_step": elapsed / steps * 1e3, "value": world * B * H * steps / elapsed, "roofline": None}
+        if rank == 0 and profile_steps > 0:
+            res["roofline"] = kernel_roofline(step, workload, precision, profile_steps, res["ms_per_step"])
+        return res
+
+    def kernel_roofline(step, workload, precision, profile_steps, step_ms):
         # The profiled pass launches kernel by kernel with an event after each.  The host needs longer
         # per launch than a small kernel runs, so queue some tens of ms of unrelated work first: the
         # launches then wait in the stream and run back to back, as they do in the graph replay.
@@ -303,18 +339,18 @@ def main():
         N.prof_enable(True)
         for _ in range(4):
             pad = torch.mm(pad, pad).clamp_(-1.0, 1.0)
-        for _ in range(args.profile_steps):
+        for _ in range(profile_steps):
             step()
         torch.cuda.synchronize()
         summ = N.prof_summary()
         N.prof_enable(False)
+        del pad
         # An event between two kernels costs the stream a few microseconds of its own.  The timed region
-        # above ran the same launches without events, so the difference between the two totals, spread
+        # ran the same launches without events, so the difference between the two totals, spread
         # over the launches, is that cost; it is taken off every launch.
         n_launch = sum(r["launches"] for r in summ.values())
-        ev_ms_per_step = sum(r["ms"] for r in summ.values()) / args.profile_steps
-        step_ms = elapsed / args.steps * 1e3
-        event_cost_ms = max(0.0, (ev_ms_per_step - step_ms) / (n_launch / args.profile_steps))
+        ev_ms_per_step = sum(r["ms"] for r in summ.values()) / profile_steps
+        event_cost_ms = max(0.0, (ev_ms_per_step - step_ms) / (n_launch / profile_steps))
         for r in summ.values():
             r["ms_net"] = max(r["ms"] - event_cost_ms * r["launches"], 0.05 * r["ms"])
         name, rec = max(summ.items(), key=lambda kv: kv[1]["ms_net"])
@@ -323,22 +359,46 @@ def main():
         # f32_split: an fp32-accurate product costs six bf16 MFMA products (exact three-way operand split),
         # so the ceiling for fp32 work on that pipe is the bf16 peak / 6
         mfma_peak = MFMA_F32_TFLOPS
-        if name == "k_linear_big":
+        if name in MFMA_CLASSES:
             mfma_peak = {"bf16": MFMA_BF16_TFLOPS, "f32_split": MFMA_BF16_TFLOPS / 6.0}.get(precision, MFMA_F32_TFLOPS)
         if ai >= mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
             ach = rec["flops"] / rec["launches"] / per_launch_s / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s", "frac": ach / mfma_peak}
+            if precision == "f32_split":
+                roofline["frac_of_f32_mfma_peak"] = ach / MFMA_F32_TFLOPS
         else:
             ach = rec["bytes"] / rec["launches"] / per_launch_s / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-        roofline.update(traffic=pmc_traffic(args.workload, name), kernel=name,
+        traffic, source = pmc_traffic(workload, name)
+        roofline.update(traffic=traffic, traffic_source=source, kernel=name,
                         algorithmic_bytes_per_launch=rec["bytes"] / rec["launches"],
                         algorithmic_flops_per_launch=rec["flops"] / rec["launches"],
-                        launches_per_step=rec["launches"] / args.profile_steps, avg_launch_us=per_launch_s * 1e6,
+                        launches_per_step=rec["launches"] / profile_steps, avg_launch_us=per_launch_s * 1e6,
                         event_cost_us_removed_per_launch=event_cost_ms * 1e3,
                         share_of_kernel_time=rec["ms_net"] / sum(r["ms_net"] for r in summ.values()),
-                        kernels={k: {"us_per_step": v["ms_net"] * 1e3 / args.profile_steps,
-                                     "launches_per_step": v["launches"] / args.profile_steps} for k, v in summ.items()})
+                        kernels={k: {"us_per_step": v["ms_net"] * 1e3 / profile_steps,
+                                     "launches_per_step": v["launches"] / profile_steps} for k, v in summ.items()})
+        return roofline
+
+    head = measure_imagine(args.workload, args.steps, args.warmup, args.profile_steps)
+    B, precision, elapsed, roofline = head["B"], head["precision"], head["elapsed"], head["roofline"]
+
+    # beside the headline (default workload only): the same block with the gather tables rebuilt before every block,
+    # and the large-batch configuration (4096 start states: the MFMA-bound case) in both fp32 forms
+    extras = {}
+    if args.workload == "imagine16" and not args.no_extras:
+        r = measure_imagine("imagine16", args.steps, min(args.warmup, 10), 0, repack=True)
+        extras["with_table_repack"] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
+                                       "note": "one-hot gather tables rebuilt from the weights before every block (seven "
+                                               "launches), as after an optimiser step in training"}
+        c3 = {}
+        for wl in ("imagine4096", "imagine4096_split"):
+            r = measure_imagine(wl, 20, 5, 3)
+            c3[r["precision"]] = {"value": r["value"], "unit": "imagined latent steps/s", "ms_per_step": r["ms_per_step"],
+                                  "steps": r["steps"], "warmup": r["warmup"], "B_per_gpu": r["B"], "H": H,
+                                  "algorithmic_tflops": r["value"] * FLOP_PER_LATENT_STEP / 1e12, "roofline": r["roofline"]}
+        extras["c3"] = c3
+        torch.cuda.empty_cache()
 
     # the three HBM-bound kernels of the path at device-filling sizes (they are single 6-us launches inside the
     # block above): achieved GB/s against the 8 TB/s peak, algorithmic bytes / event-timed launch
@@ -371,6 +431,7 @@ def main():
             "stream_kernels": stream_kernels,
             "train": train,
         }
+        line.update(extras)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, wm, actor, critic, 16, H)
             line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
@@ -388,7 +449,9 @@ def main():
             import faulthandler
             faulthandler.dump_traceback(file=sys.stderr, all_threads=True)   # where each rank is stuck
             emit({"error": f"timeout after {args.train_limit_s} s"})
-            os._exit(0)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(1)       # the headline line is out; a stalled training section must not look like success
 
         guard = threading.Timer(args.train_limit_s, give_up)
         guard.daemon = True
@@ -402,11 +465,14 @@ def main():
         guard.cancel()
 
     emit(train)
+    failed = isinstance(train, dict) and "error" in train
+    sys.stdout.flush()
+    sys.stderr.flush()
     if world > 1:
         # every number is out; leave without the group's teardown, which would wait for a rank that failed
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        os._exit(1 if failed else 0)
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -74,6 +74,7 @@ class FlatGrads:
         self.params: List[torch.nn.Parameter] = []
         self.offsets: List[int] = []
         self.static = False
+        self.seen = None          # static mode, once gradients were gathered: slots that have received one at least once
         self.channels_last_kernels = os.environ.get("DRM_TOWER_CHANNELS_LAST", "0") == "1" and any(
             p.is_cuda for p in module.parameters())
         if static:
@@ -109,20 +110,22 @@ class FlatGrads:
         self.flat = torch.zeros(o, dtype=ref.dtype, device=ref.device)
         self.flat_params = torch.zeros(o, dtype=ref.dtype, device=ref.device)
 
-        def slot(buf, p, off):
-            # convolution kernels keep their logical (O, I, kh, kw) shape; with channels-last towers their slot is laid
-            # out (O, kh, kw, I), the format the convolution backend then takes without transposing them on every call
-            if p.dim() == 4 and self.channels_last_kernels:
-                return buf[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
-            return buf[off:off + p.numel()].view_as(p)
-
-        self.views = [slot(self.flat, p, off) for p, off in zip(self.params, self.offsets)]
+        self.views = [self.slot_view(self.flat, i) for i in range(len(self.params))]
         self._missing = None
         with torch.no_grad():
-            for p, off in zip(self.params, self.offsets):
-                pv = slot(self.flat_params, p, off)
+            for i, p in enumerate(self.params):
+                pv = self.slot_view(self.flat_params, i)
                 pv.copy_(p.data)
                 p.data = pv
+
+    def slot_view(self, buf: torch.Tensor, i: int) -> torch.Tensor:
+        """Parameter ``i``'s slot of a flat buffer laid out like ``flat``, with the parameter's logical shape.
+        Convolution kernels keep their logical (O, I, kh, kw) shape; with channels-last towers their slot is laid
+        out (O, kh, kw, I), the format the convolution backend then takes without transposing them on every call."""
+        p, off = self.params[i], self.offsets[i]
+        if p.dim() == 4 and self.channels_last_kernels:
+            return buf[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+        return buf[off:off + p.numel()].view_as(p)
 
     def zero(self) -> None:
         if self.flat is None or self.static:
@@ -138,6 +141,7 @@ class FlatGrads:
             for i in missing:
                 self.views[i].zero_()
             self._missing = missing
+            self.seen = (self.seen or set()) | set(have)
         with torch.no_grad():
             torch._foreach_copy_([self.views[i] for i in have], [self.params[i].grad for i in have])
 

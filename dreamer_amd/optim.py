@@ -38,26 +38,45 @@ class FlatAdam:
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.grads.zero()
 
+    def _param_ids(self):
+        """Index of each flat-buffer parameter in ``list(module.parameters())``: the ids torch.optim.Adam gives the
+        parameters when it is built from ``module.parameters()`` as the reference does (lib/trainer.py:95-103), frozen
+        ones (the critic's ``slow.*`` copy, lib/critic.py:51-53) included in the count."""
+        everything = list(self.grads.module.parameters())
+        where = {id(p): i for i, p in enumerate(everything)}
+        return len(everything), [where[id(p)] for p in self.grads.params]
+
     def state_dict(self):
-        """torch.optim.Adam's layout over the parameters of the flat buffer, in order."""
+        """torch.optim.Adam's layout: one param group listing every parameter of the module, and state for the
+        parameters that have received a gradient at least once (torch creates a parameter's state at its first step
+        with a gradient; ``seq.norm.*`` and frozen copies never get one)."""
         g = self.grads
+        n_all, ids = self._param_ids()
+        seen = g.seen if g.seen is not None else range(len(g.params))
         state = {}
-        for i, (p, off) in enumerate(zip(g.params, g.offsets)):
+        for slot in sorted(seen):
+            p, off = g.params[slot], g.offsets[slot]
             sl = slice(off, off + p.numel())
-            state[i] = {"step": self.step_count.reshape(()).clone(), "exp_avg": self.exp_avg[sl].view_as(p).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[sl].view_as(p).clone()}
+            state[ids[slot]] = {"step": self.step_count.reshape(()).clone(), "exp_avg": g.slot_view(self.exp_avg, slot).clone(),
+                                "exp_avg_sq": g.slot_view(self.exp_avg_sq, slot).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": True, "differentiable": False, "fused": True,
-                 "decoupled_weight_decay": False, "params": list(range(len(g.params)))}
+                 "decoupled_weight_decay": False, "params": list(range(n_all))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd) -> None:
+        """Accepts what ``state_dict`` writes and what ``torch.optim.Adam(module.parameters()).state_dict()`` writes."""
         g = self.grads
-        for i, (p, off) in enumerate(zip(g.params, g.offsets)):
-            st = sd["state"].get(i)
+        n_all, ids = self._param_ids()
+        listed = sum(len(grp["params"]) for grp in sd["param_groups"])
+        if listed != n_all:
+            raise ValueError(f"optimizer state lists {listed} parameters, the module has {n_all}")
+        for slot, pid in enumerate(ids):
+            st = sd["state"].get(pid)
             if st is None:
                 continue
-            sl = slice(off, off + p.numel())
-            self.exp_avg[sl].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[sl].copy_(st["exp_avg_sq"].reshape(-1))
+            g.slot_view(self.exp_avg, slot).copy_(st["exp_avg"])
+            g.slot_view(self.exp_avg_sq, slot).copy_(st["exp_avg_sq"])
             self.step_count.fill_(float(st["step"]))
+            if g.seen is not None:
+                g.seen.add(slot)

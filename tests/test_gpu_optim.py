@@ -100,3 +100,42 @@ def test_state_dict_round_trips_through_torch_adam():
     for pa, pb, pc in zip(a.parameters(), b.parameters(), c.parameters()):
         assert torch.equal(pa, pc)
         assert float((pa - pb).abs().max()) <= 2e-6 * max(float(pa.abs().max()), 1e-3)
+
+
+def test_critic_checkpoint_loads_into_the_reference_optimiser():
+    """The reference builds Adam(critic.parameters()) (lib/trainer.py:101), whose single group also lists the frozen
+    ``slow.*`` copy (lib/critic.py:51-53).  The flat optimiser's state dict must list as many parameter ids, carry
+    state only for parameters that received gradients, load into that torch optimiser, and accept its state dict."""
+    from dreamer_amd.critic import Critic
+    from dreamer_amd.world_model import WorldModelState
+    torch.manual_seed(0)
+    mk = lambda: Critic(64 + 4 * 32, 32, 2, 255, -20.0, 20.0, 0.98, 1.0).to(DEV)
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    ga = FlatGrads(a, static=True)
+    oa = FlatAdam(ga, lr=3e-5, eps=1e-5, clip=100.0)
+    ob = torch.optim.Adam(b.parameters(), lr=3e-5, eps=1e-5, fused=True)
+    h = torch.randn(6, 5, 64, device=DEV)
+    z = torch.nn.functional.one_hot(torch.randint(0, 32, (6, 5, 4), device=DEV), 32).float()
+    ret = torch.randn(6, 5, device=DEV) * 3
+    for _ in range(2):
+        ga.zero(); ob.zero_grad()
+        a.loss(WorldModelState(h=h, z=z), ret).backward()
+        b.loss(WorldModelState(h=h, z=z), ret).backward()
+        ga.sync(); oa.step()
+        nn.utils.clip_grad_norm_(b.parameters(), 100.0); ob.step()
+    sd, sd_ref = oa.state_dict(), ob.state_dict()
+    n_all = len(list(a.parameters()))
+    assert sd["param_groups"][0]["params"] == sd_ref["param_groups"][0]["params"] == list(range(n_all))
+    assert sorted(sd["state"]) == sorted(sd_ref["state"]) and len(sd["state"]) == n_all // 2
+    fresh = torch.optim.Adam(mk().parameters(), lr=3e-5, eps=1e-5, fused=True)
+    fresh.load_state_dict(sd)                      # what the reference-side loader would do with the checkpoint
+    for i, st in sd_ref["state"].items():
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert float((sd["state"][i][key] - st[key]).abs().max()) <= 1e-5 * float(st[key].abs().max()) + 1e-12
+    c = mk()
+    c.load_state_dict(a.state_dict())
+    oc = FlatAdam(FlatGrads(c, static=True), lr=3e-5, eps=1e-5, clip=100.0)
+    oc.load_state_dict(sd_ref)                     # and the other way round
+    assert float(oc.step_count) == 2.0
+    assert float((oc.exp_avg - oa.exp_avg).abs().max()) <= 1e-5 * float(oa.exp_avg.abs().max())
