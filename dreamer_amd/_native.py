@@ -126,6 +126,7 @@ SIGNATURES = {
     "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
     "drm_imagine_block_f32": (C.c_int, [C.POINTER(drm_imagine_weights), C.POINTER(drm_imagine_io), C.c_void_p]),
     "drm_graph_cache_clear": (C.c_int, []),
+    "drm_imagine_block_noalloc_f32": (C.c_int, [C.POINTER(drm_imagine_weights), C.POINTER(drm_imagine_io), C.c_void_p]),
     "drm_pack_observe_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
     "drm_pack_observe": (C.c_int, [C.POINTER(drm_observe_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_observe_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),

@@ -1240,6 +1240,52 @@ extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_ima
     return DRM_OK;
 }
 
+// ---- the same block for callers that must not allocate ------------------------------------------
+namespace drm {
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)DRM_IMAGINE_NOALLOC_MAX_WORKSPACE;
+// Workspace of drm_imagine_block_noalloc_f32: part of the library's device image, so every GPU the library
+// runs on holds its own copy at its own address from the moment the code object is loaded there.
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[SCRATCH_MAX_DEVICES] = {};   // device address of `scratch` per device ordinal
+
+// Device address of the current device's copy of `scratch` (looked up once per device, with that device current:
+// in host code the array's name is only a handle for this lookup, never an address a kernel may use).
+static int scratch_of_current_device(void** out) {
+    int dev = 0;
+    DRM_HIP(hipGetDevice(&dev));
+    DRM_REQUIRE(dev >= 0 && dev < SCRATCH_MAX_DEVICES, DRM_ENOTSUP, "device ordinal %d (at most %d devices)", dev, SCRATCH_MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        DRM_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        DRM_REQUIRE(p != nullptr && aligned16(p), DRM_EHIP, "no usable address for the static workspace on device %d", dev);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return DRM_OK;
+}
+}  // namespace drm
+
+extern "C" int drm_imagine_block_noalloc_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
+    DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
+    DRM_REQUIRE(io->use_graph == 0, DRM_EINVAL, "use_graph must be 0: instantiating a graph allocates");
+    DRM_REQUIRE(!prof_on(), DRM_EINVAL, "per-kernel timing is enabled (drm_prof_enable): it creates events");
+    if (int rc = check_dims(w->dims)) return rc;
+    DRM_REQUIRE(io->B >= 1 && io->H >= 1 && (int64_t)io->B * io->H < (1 << 30), DRM_EINVAL, "B=%d H=%d", io->B, io->H);
+    const size_t need = ws_layout(w->dims, io->B, io->H).total * sizeof(float);
+    DRM_REQUIRE(need <= STATIC_SCRATCH_BYTES, DRM_ENOTSUP,
+                "B=%d x H=%d at these widths needs a workspace of %zu bytes; the static workspace of this entry point holds "
+                "%zu (use drm_imagine_block_f32 with a caller workspace)", io->B, io->H, need, STATIC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    if (int rc = scratch_of_current_device(&ws)) return rc;
+    drm_imagine_io local = *io;
+    local.workspace = ws;
+    local.workspace_bytes = STATIC_SCRATCH_BYTES;
+    return imagine_enqueue(w, &local, stream);
+}
+
 #ifdef DRM_STAMPS
 extern "C" int drm_debug_set_stamp_buffer(void* p) {
     DRM_HIP(hipMemcpyToSymbol(HIP_SYMBOL(drm::g_stamp_buf), &p, sizeof(p)));

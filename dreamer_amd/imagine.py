@@ -126,13 +126,16 @@ class ImagineEngine:
             noise: Optional[Dict[str, torch.Tensor]] = None, forced_actions: Optional[torch.Tensor] = None,
             forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
             want_prior_logits: bool = False, want_sampled: bool = False, start_zidx: Optional[torch.Tensor] = None,
-            repack: bool = True, persistent: bool = False, precision: str = "f32") -> Dict[str, torch.Tensor]:
+            repack: bool = True, persistent: bool = False, precision: str = "f32",
+            noalloc: bool = False) -> Dict[str, torch.Tensor]:
         """Run the block.  With ``persistent=True`` all inputs are staged into, and all outputs
         returned as, buffers that live as long as the engine (overwritten by the next call with the
         same shape); every device address is then the same from call to call and the native side
         replays the block as one recorded hipGraph.  ``precision="bf16"``: the matrix products of the
         large-row path take bf16 inputs (fp32 accumulation, everything else fp32).  ``precision="f32_split"``:
-        those products at fp32 accuracy on the bf16 matrix pipe (exact three-way split of both operands)."""
+        those products at fp32 accuracy on the bf16 matrix pipe (exact three-way split of both operands).
+        ``noalloc=True``: the library's entry point that takes no workspace (it uses a static device array of its own,
+        for at most a few dozen trajectories) and never records a graph."""
         d, dev = self.dims, self.device
         B, H = start.h.shape[0], int(horizon)
         if repack:
@@ -169,7 +172,7 @@ class ImagineEngine:
             else:
                 ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
         assert ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K)
-        ws = self._workspace(B, H)
+        ws = None if noalloc else self._workspace(B, H)
         io = N.drm_imagine_io()
         io.B, io.H = B, H
         io.h0, io.zidx0, io.expo_a, io.expo_z = h0.data_ptr(), zidx0.data_ptr(), ea.data_ptr(), ez.data_ptr()
@@ -183,10 +186,15 @@ class ImagineEngine:
                                                        out["values"].data_ptr())
         io.v_last_out, io.lam_returns_out = out["v_last"].data_ptr(), out["lam_returns"].data_ptr()
         io.gamma, io.lam = float(gamma), float(lam)
-        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        io.use_graph = 1 if (persistent and forced_actions is None and forced_zidx is None) else 0
         io.precision = {"f32": 0, "bf16": 1, "f32_split": 2}[precision]
         w = self._weights()
+        if noalloc:
+            io.workspace, io.workspace_bytes, io.use_graph = None, 0, 0
+            N.check(N.lib().drm_imagine_block_noalloc_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)),
+                    "drm_imagine_block_noalloc_f32")
+            return out
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        io.use_graph = 1 if (persistent and forced_actions is None and forced_zidx is None) else 0
         N.check(N.lib().drm_imagine_block_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_imagine_block_f32")
         return out
 

@@ -257,6 +257,22 @@ int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io
 /* Destroys the recorded graphs (at most 16 are kept, oldest evicted first). */
 int drm_graph_cache_clear(void);
 
+/* The same block for callers that cannot allocate device memory or pass a workspace: code running under a
+ * HIP graph capture of the caller's own, tight serving loops, harnesses that forbid hipMalloc.  No counterpart
+ * in the reference.  Same arguments, kernels and results as drm_imagine_block_f32, except:
+ *   - io->workspace / io->workspace_bytes are ignored: the workspace is a file-scope device array of
+ *     DRM_IMAGINE_NOALLOC_MAX_WORKSPACE bytes inside the library (each GPU the library runs on holds its own
+ *     copy until the process ends).  A call whose drm_imagine_workspace_bytes(dims, B, H) exceeds that is
+ *     rejected with DRM_ENOTSUP (at the default widths, H = 15: up to 72 trajectories);
+ *   - io->use_graph must be 0 and per-kernel timing must be off (both create runtime objects);
+ *   - it calls no hipMalloc / hipFree or any other allocating routine; the array's device address is looked up
+ *     once per device on the first call made with that device current;
+ *   - every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two
+ *     threads) race.  Nothing in the array needs to start at zero; each region is written before it is read
+ *     within a call, so the contents left by an earlier call are never seen. */
+#define DRM_IMAGINE_NOALLOC_MAX_WORKSPACE (16u << 20)
+int drm_imagine_block_noalloc_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream);
+
 /* ---- observe (posterior) recurrence: the time loop of lib/world_model.py:563-589 ---------------
  * For t = 0..T-1 and B replayed sequences (c = c_prev[b,t] in {0,1}):
  *     z_in  = c ? z_{t-1} : one_hot(argmax softmax(1/K - log expo_reset[t,b]))   (lib/world_model.py:57-61)
