@@ -1,5 +1,7 @@
-"""Two data-parallel ranks on one GPU (gloo, device tensors staged through the host): the flat-gradient
-gather + all-reduce + flat Adam step of each rank equals a single process on the concatenated batch."""
+"""Two data-parallel ranks: the flat-gradient gather + all-reduce + flat Adam step of each rank equals a single
+process on the concatenated batch.  On one GPU the ranks share the device and the collectives run over gloo (device
+tensors staged through the host); with two or more GPUs visible the same check runs with one rank per GPU over
+RCCL (torch's ``nccl`` backend), the path ``bench.py --gpus N`` and ``train`` take under torchrun."""
 import os
 import socket
 
@@ -19,11 +21,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port):
+def _worker(rank, world, port, backend):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        dev = torch.device("cuda:0")
         from dreamer_amd import dist as D
         from dreamer_amd.optim import FlatAdam
         d, salt, B = DIMS["small"], 5, 4
@@ -67,4 +73,9 @@ def _worker(rank, world, port):
 
 
 def test_two_ranks_on_one_gpu_equal_single_process():
-    mp.spawn(_worker, args=(2, _free_port()), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), "gloo"), nprocs=2, join=True)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one rank per GPU over RCCL")
+def test_two_ranks_over_rccl_equal_single_process():
+    mp.spawn(_worker, args=(2, _free_port(), "nccl"), nprocs=2, join=True)
