@@ -52,6 +52,35 @@ class ReplayBuffer:
         self.full = self.full or self.idx + n >= self.capacity
         self.idx = (self.idx + n) % self.capacity
 
+    # ---- persistence (the reference keeps its buffer in memory only and saves nothing: lib/trainer.py:326-335) ----
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The filled part of the ring and its write position, as host tensors only (a file written with
+        ``torch.save`` of this dict loads with ``torch.load(..., weights_only=True)``)."""
+        n = len(self)
+        return {"observations": self.observations[:n].cpu(), "actions": self.actions[:n].cpu(),
+                "rewards": self.rewards[:n].cpu(), "continues": self.continues[:n].cpu(),
+                "meta": torch.tensor([self.capacity, self.idx, int(self.full), self.seq_len], dtype=torch.int64)}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        cap, idx, full, _ = (int(v) for v in sd["meta"])
+        if cap != self.capacity or tuple(sd["observations"].shape[1:]) != self.obs_shape:
+            raise ValueError(f"replay file holds capacity {cap}, frames {tuple(sd['observations'].shape[1:])}; this ring has "
+                             f"capacity {self.capacity}, frames {self.obs_shape}")
+        n = sd["actions"].numel()
+        if n != (cap if full else idx):
+            raise ValueError("replay file is inconsistent: stored rows do not match its write position")
+        self.observations[:n].copy_(sd["observations"])
+        self.actions[:n].copy_(sd["actions"])
+        self.rewards[:n].copy_(sd["rewards"])
+        self.continues[:n].copy_(sd["continues"])
+        self.idx, self.full = idx, bool(full)
+
+    def save(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load(self, path: str) -> None:
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+
     def draw_starts(self, batch_size: int) -> np.ndarray:
         assert len(self) >= self.seq_len, "Not enough data to sample."
         if self.full:

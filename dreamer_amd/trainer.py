@@ -340,6 +340,15 @@ class Learner:
                 "critic": self.critic.state_dict(), "optim_world_model": self.optim_world_model.state_dict(),
                 "optim_actor": self.optim_actor.state_dict(), "optim_critic": self.optim_critic.state_dict()}
 
+    def load_state_dicts(self, sd) -> None:
+        """Restore models and optimisers from a checkpoint of the layout ``state_dicts`` writes (the reference's,
+        lib/trainer.py:326-335).  Parameters are copied in place: the flat parameter buffers, the recorded
+        graphs and the packed gather tables of the engines (rebuilt from the weights on every call) stay valid."""
+        for name in ("world_model", "actor", "critic"):
+            getattr(self, name).load_state_dict(sd[name])
+        for name in ("optim_world_model", "optim_actor", "optim_critic"):
+            getattr(self, name).load_state_dict(sd[name])
+
 
 def _log(writer, learner: Learner, out, step: int, ups: float):
     cfg = learner.cfg
@@ -377,7 +386,63 @@ def _log(writer, learner: Learner, out, step: int, ups: float):
           f"Critic Loss: {out['critic_loss'].item():.3f}, Updates/sec: {ups:.3f}")
 
 
-def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
+def _rng_snapshot():
+    """Host and device generator states as tensors (loadable with ``weights_only=True``)."""
+    kind, keys, pos, has_gauss, cached = np.random.get_state()
+    snap = {"numpy_keys": torch.from_numpy(np.asarray(keys, dtype=np.int64)),
+            "numpy_pos": torch.tensor([int(pos), int(has_gauss)], dtype=torch.int64),
+            "numpy_gauss": torch.tensor([float(cached)], dtype=torch.float64), "torch_cpu": torch.get_rng_state()}
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        snap["torch_cuda"] = torch.cuda.get_rng_state()
+    return snap
+
+
+def _rng_restore(snap) -> None:
+    pos, has_gauss = (int(v) for v in snap["numpy_pos"])
+    np.random.set_state(("MT19937", snap["numpy_keys"].numpy().astype(np.uint32), pos, has_gauss, float(snap["numpy_gauss"][0])))
+    torch.set_rng_state(snap["torch_cpu"].cpu())
+    if "torch_cuda" in snap and torch.cuda.is_available():
+        torch.cuda.set_rng_state(snap["torch_cuda"].cpu())
+
+
+def save_checkpoint(directory: str, learner: "Learner", counters: Dict[str, float], buffer: Optional[ReplayBuffer] = None) -> None:
+    """``ckpt.pth`` with the reference's six entries (lib/trainer.py:326-335) plus ``trainer_state`` (update / step
+    counters, train-ratio credit, generator states; tensors and plain numbers only), written to a temporary name and
+    moved into place; with ``buffer`` the replay ring goes to ``replay.pth`` beside it."""
+    os.makedirs(directory, exist_ok=True)
+    sd = learner.state_dicts()
+    sd["trainer_state"] = {"counters": {k: float(v) for k, v in counters.items()}, "rng": _rng_snapshot()}
+    tmp = os.path.join(directory, "ckpt.pth.tmp")
+    torch.save(sd, tmp)
+    os.replace(tmp, os.path.join(directory, "ckpt.pth"))
+    if buffer is not None:
+        tmp = os.path.join(directory, "replay.pth.tmp")
+        buffer.save(tmp)
+        os.replace(tmp, os.path.join(directory, "replay.pth"))
+
+
+def load_checkpoint(path: str, learner: "Learner", buffer: Optional[ReplayBuffer] = None) -> Dict[str, float]:
+    """Restore a learner (and, when ``replay.pth`` lies beside the checkpoint, the replay ring) from ``path``
+    (a directory or the ``ckpt.pth`` file).  Files are read with ``weights_only=True``: nothing in them is executed.
+    A checkpoint written by the reference (no ``trainer_state``) restores models and optimisers and returns {}."""
+    ckpt = os.path.join(path, "ckpt.pth") if os.path.isdir(path) else path
+    sd = torch.load(ckpt, map_location=learner.cfg.device, weights_only=True)
+    learner.load_state_dicts(sd)
+    replay = os.path.join(os.path.dirname(ckpt), "replay.pth")
+    if buffer is not None and os.path.exists(replay):
+        buffer.load(replay)
+    extra = sd.get("trainer_state")
+    if not extra:
+        return {}
+    _rng_restore(extra["rng"])
+    return dict(extra["counters"])
+
+
+def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True, resume: Optional[str] = None,
+          save_replay: bool = False):
+    """The reference's entry point (lib/trainer.py:16).  ``resume``: a checkpoint directory or file to continue from
+    (the reference only saves); ``save_replay``: write the replay ring beside every checkpoint so that a resumed
+    run continues with the data it had."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         cfg.device = D.init_from_env(cfg.device)
     is_main = D.rank() == 0
@@ -403,7 +468,14 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
     updates_done = update_counter = policy_steps = 0
     policy = ActingPolicy(wm, actor, cfg.device, obs_shape)
     current_obs = None
-    for _ in range(cfg.num_iterations):
+    if resume is not None:
+        c = load_checkpoint(resume, learner, buffer)
+        updates_done, policy_steps = int(c.get("updates_done", 0)), int(c.get("policy_steps", 0))
+        update_credit = float(c.get("update_credit", 0.0))
+        policy.reset()    # the environment starts a new episode; the recurrent state does too
+        if is_main and verbose:
+            print(f"Resumed from {resume}: {updates_done} updates, {policy_steps} env steps, {len(buffer)} stored transitions")
+    for _ in range(max(cfg.num_iterations - policy_steps, 0)):
         if current_obs is None:
             current_obs, _ = env.reset()
         action = policy.act(current_obs)
@@ -437,12 +509,15 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True):
                 log_wm_reconstruction_video(cfg, writer, env, wm, actor, updates_done)
                 log_wm_imagination_video(cfg, writer, env, wm, actor, updates_done)
                 wm.train(); actor.train()
-            if is_main and updates_done % cfg.save_interval == 0 and updates_done > 0 and cfg.checkpoint_dir is not None:
-                os.makedirs(cfg.checkpoint_dir, exist_ok=True)
-                torch.save(learner.state_dicts(), os.path.join(cfg.checkpoint_dir, "ckpt.pth"))
-                print(f"Saved model checkpoint to {cfg.checkpoint_dir}")
             update_credit -= credits_per_update
             updates_done += 1
             update_counter += 1
+            if is_main and (updates_done - 1) % cfg.save_interval == 0 and updates_done > 1 and cfg.checkpoint_dir is not None:
+                # after update number `updates_done - 1` (the reference's save point, lib/trainer.py:326-335), with
+                # the counters as they stand once that update is accounted for
+                save_checkpoint(cfg.checkpoint_dir, learner, {"updates_done": updates_done, "policy_steps": policy_steps,
+                                                              "update_credit": update_credit},
+                                buffer if save_replay else None)
+                print(f"Saved model checkpoint to {cfg.checkpoint_dir}")
     env.close()
     return learner

@@ -128,3 +128,44 @@ def test_train_loop_end_to_end_on_the_gpu():
             assert torch.isfinite(p).all()
     finally:
         Config.num_latents, Config.classes_per_latent = 32, 32
+
+
+def test_checkpoint_resume_on_the_gpu(tmp_path):
+    """Checkpoint written from the flat optimisers and the HBM replay ring, restored into a fresh learner / ring with
+    ``weights_only=True`` loads: parameters (in place, inside the flat buffers), Adam moments, replay bytes, counters."""
+    import numpy as np
+    from dreamer_amd.config import Config
+    from dreamer_amd.trainer import Learner, load_checkpoint, train
+    from dreamer_amd.utils import SyntheticPixelEnv
+    try:
+        Config.num_latents, Config.classes_per_latent = 8, 32
+        torch.manual_seed(0); np.random.seed(0)
+        cfg = Config(env_id="synthetic", device=DEV, num_iterations=14, replay_capacity=64, batch_size=4,
+                     batch_length=6, train_ratio=24.0, imagination_horizon=3, hidden_size=64, base_cnn_channels=4,
+                     mlp_hidden_units=64, log_interval=10 ** 9, save_interval=4, video_interval=10 ** 9, checkpoint_dir=str(tmp_path))
+        first = train(cfg, env=SyntheticPixelEnv(16, n_actions=3, episode_len=7), verbose=False, save_replay=True)
+        sd = torch.load(tmp_path / "ckpt.pth", weights_only=True, map_location="cpu")
+        learner = Learner(cfg, (3, 16, 16), 3)
+        ring = ReplayBuffer(64, (3, 16, 16), cfg.batch_length, DEV)
+        flat_ptr = learner.g_wm.flat_params.data_ptr()
+        counters = load_checkpoint(str(tmp_path), learner, ring)
+        assert counters["updates_done"] == sd["trainer_state"]["counters"]["updates_done"] >= 5
+        assert learner.g_wm.flat_params.data_ptr() == flat_ptr
+        for k, v in learner.world_model.state_dict().items():
+            assert torch.equal(v.cpu(), sd["world_model"][k]), k
+        for p in learner.world_model.parameters():   # still views of the flat buffer
+            assert flat_ptr <= p.data_ptr() < flat_ptr + learner.g_wm.flat_params.numel() * 4
+        mine, theirs = learner.optim_world_model.state_dict(), sd["optim_world_model"]
+        assert sorted(mine["state"]) == sorted(theirs["state"])
+        for i in theirs["state"]:
+            assert torch.equal(mine["state"][i]["exp_avg"].cpu(), theirs["state"][i]["exp_avg"])
+        n = int(counters["policy_steps"])
+        assert len(ring) == n and torch.equal(ring.observations[:n], first_ring_rows(tmp_path, n))
+        out = learner.update(ring.sample(cfg.batch_size, want_f32=True))     # and it trains on from there
+        assert torch.isfinite(out["world_model_loss"]).all()
+    finally:
+        Config.num_latents, Config.classes_per_latent = 32, 32
+
+
+def first_ring_rows(tmp_path, n):
+    return torch.load(tmp_path / "replay.pth", weights_only=True)["observations"][:n].to(DEV)
