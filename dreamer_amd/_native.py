@@ -114,6 +114,14 @@ SIGNATURES = {
                              + [C.c_void_p] * 5),
     "drm_mse_rows_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_mse_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "drm_critic_loss_forward": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                          C.c_void_p]),
+    "drm_critic_loss_backward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                           C.c_void_p]),
+    "drm_ema_multi": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_double,
+                                C.c_void_p]),
+    "drm_percentile_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_convt_k4s2_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_adam_workspace_bytes": (C.c_size_t, []),
     "drm_adam_flat_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 5 + [C.c_void_p] * 4),
@@ -121,6 +129,9 @@ SIGNATURES = {
     "drm_fused_linear_f32": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_split": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
+    "drm_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "drm_gemm_f32": (C.c_int, [C.c_int32] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_pack_imagine_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
     "drm_pack_imagine": (C.c_int, [C.POINTER(drm_imagine_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_imagine_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
@@ -346,6 +357,74 @@ def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int =
     else:
         check(lib().drm_fused_linear_f32(C.byref(a), stream_ptr(x.device)), "drm_fused_linear_f32")
     return y
+
+
+def ema_multi(srcs, dsts, decay: float) -> None:
+    """dst <- dst * decay + src * (1 - decay) for every (src, dst) pair of dense fp32 device tensors, one launch."""
+    n = len(dsts)
+    if n == 0:
+        return
+    require_cuda(*srcs, *dsts)
+    for s, d in zip(srcs, dsts):
+        _dense(s, torch.float32, "src"); _dense(d, torch.float32, "dst")
+        if s.numel() != d.numel():
+            raise ValueError("ema_multi: tensors of a pair differ in size")
+    sp = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dp = (C.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    ne = (C.c_int64 * n)(*[t.numel() for t in dsts])
+    check(lib().drm_ema_multi(n, sp, dp, ne, float(decay), stream_ptr(dsts[0].device)), "drm_ema_multi")
+
+
+def _gemm_operand_ok(t: torch.Tensor) -> bool:
+    return (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda and t.stride(1) == 1 and t.stride(0) % 4 == 0
+            and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0)
+
+
+def gemm_ok(a: torch.Tensor, b: torch.Tensor, trans_a: bool, trans_b: bool) -> bool:
+    """Whether ``gemm`` takes these operands (dense-row fp32 device matrices, 16-byte aligned rows)."""
+    if not (_gemm_operand_ok(a) and _gemm_operand_ok(b)):
+        return False
+    k = a.shape[0] if trans_a else a.shape[1]
+    return (trans_a and trans_b) or k % 4 == 0
+
+
+_gemm_ws = {}
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, bias: Optional[torch.Tensor] = None):
+    """op(a) @ op(b) (+ bias) on the library's fp32 MFMA kernel.
+    trans_a=False: a is (M, K); True: a is (K, M).  trans_b=False: b is (N, K) (a Linear weight); True: b is (K, N)."""
+    K, M = (a.shape[0], a.shape[1]) if trans_a else (a.shape[1], a.shape[0])
+    Kb, N = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    if K != Kb:
+        raise ValueError(f"gemm: reduction extents differ ({K} vs {Kb})")
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    need = lib().drm_gemm_workspace_bytes(M, N, K)
+    ws = None
+    if need:
+        # one scratch buffer per device, grown on demand; launches on one stream use it one after another
+        held = _gemm_ws.setdefault(a.device, [])
+        if not held or held[-1].numel() * 4 < need:
+            # earlier, smaller buffers stay alive: a recorded graph may still point at them
+            held.append(torch.empty(need // 4 + 4, dtype=torch.float32, device=a.device))
+        ws = held[-1]
+    check(lib().drm_gemm_f32(int(trans_a), int(trans_b), M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), ptr(bias),
+                             c.data_ptr(), c.stride(0), ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(a.device)),
+          "drm_gemm_f32")
+    return c
+
+
+PERCENTILE_MAX = 16384
+
+
+def percentile_scale(x, p05, p95, decay: float, limit: float, training: bool) -> torch.Tensor:
+    """S = max(EMA(q95) - EMA(q05), limit) with the EMA buffers updated in place when training; one launch."""
+    require_cuda(x, p05, p95)
+    _dense(x, torch.float32, "x")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib().drm_percentile_scale(x.data_ptr(), x.numel(), 0.05, 0.95, float(decay), float(limit), int(training),
+                                     p05.data_ptr(), p95.data_ptr(), out.data_ptr(), stream_ptr(x.device)), "drm_percentile_scale")
+    return out
 
 
 PROF_CLASSES = 12

@@ -34,6 +34,9 @@ class EMAPercentileScale(nn.Module):
             return (self.p95 - self.p05).clamp_min(self.min_scale)
         if self.gather is not None:
             x = self.gather(x)
+        if x.is_cuda and x.numel() <= 16384:
+            from . import _native as N   # sort, both quantiles, the EMA update and the scale in one launch
+            return N.percentile_scale(x.contiguous(), self.p05, self.p95, self.decay, self.min_scale, self.training)
         lo = torch.quantile(x, 0.05)
         hi = torch.maximum(torch.quantile(x, 0.95), lo + 1e-8)
         if self.training:

@@ -59,11 +59,29 @@ class Critic(nn.Module):
     def update_slow(self):
         # parameters() yields this module's own tensors first and the slow copy's after them; the
         # zip stops at the slow copy's length, pairing each tensor with its EMA (lib/critic.py:136)
-        for p, p_slow in zip(self.parameters(), self.slow.parameters()):
+        pairs = list(zip(self.parameters(), self.slow.parameters()))
+        if pairs and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and q.is_contiguous() for p, q in pairs):
+            from . import _native as N
+            N.ema_multi([p.data for p, _ in pairs], [q.data for _, q in pairs], self.ema_decay)   # one launch
+            return
+        for p, p_slow in pairs:
             p_slow.data.mul_(self.ema_decay)
             p_slow.data.add_(p.data * (1.0 - self.ema_decay))
 
     def loss(self, model_states: WorldModelState, returns: torch.Tensor) -> torch.Tensor:
+        logits = self(model_states)
+        if logits.is_cuda and logits.dtype == torch.float32 and self.num_buckets <= 256:
+            # two-hot target, cross-entropy and the regulariser towards the slow critic from one row kernel each way
+            from . import losses as FL
+            slow_logits = None
+            if self.ema_regularizer > 0.0:
+                with torch.no_grad():
+                    slow_logits = self.slow(model_states)
+            return FL.critic_loss_rows(logits, slow_logits, returns, self.bucket_min, self.bucket_max,
+                                       max(self.ema_regularizer, 0.0)).mean()
+        return self._loss_eager(model_states, returns)
+
+    def _loss_eager(self, model_states: WorldModelState, returns: torch.Tensor) -> torch.Tensor:
         target = self._twohot(symlog(returns.detach()))
         log_probs = F.log_softmax(self(model_states), dim=-1)
         loss = -(target * log_probs).sum(dim=-1).mean()

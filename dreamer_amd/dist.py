@@ -141,7 +141,7 @@ class FlatGrads:
             for i in missing:
                 self.views[i].zero_()
             self._missing = missing
-            self.seen = (self.seen or set()) | set(have)
+            self.seen = (self.seen if self.seen is not None else set()) | set(have)
         with torch.no_grad():
             torch._foreach_copy_([self.views[i] for i in have], [self.params[i].grad for i in have])
 

@@ -70,5 +70,38 @@ def mse_rows(x_hat: torch.Tensor, x_true: torch.Tensor) -> torch.Tensor:
     return _MseRowsFn.apply(x_hat.float(), x_true.detach().float())
 
 
+class _CriticLossRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, slow_logits, returns, lo, hi, reg):
+        rows, nb = logits.shape
+        out = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        N.check(N.lib().drm_critic_loss_forward(logits.data_ptr(), N.ptr(slow_logits), returns.data_ptr(), rows, nb, lo, hi, reg,
+                                                out.data_ptr(), N.stream_ptr(logits.device)), "drm_critic_loss_forward")
+        ctx.save_for_backward(logits, slow_logits, returns)
+        ctx.conf = (lo, hi, reg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, slow_logits, returns = ctx.saved_tensors
+        lo, hi, reg = ctx.conf
+        rows, nb = logits.shape
+        d = torch.empty_like(logits)
+        N.check(N.lib().drm_critic_loss_backward(logits.data_ptr(), N.ptr(slow_logits), returns.data_ptr(), g.contiguous().data_ptr(),
+                                                 rows, nb, lo, hi, reg, d.data_ptr(), N.stream_ptr(logits.device)),
+                "drm_critic_loss_backward")
+        return d, None, None, None, None, None
+
+
+def critic_loss_rows(logits: torch.Tensor, slow_logits, returns: torch.Tensor, bucket_min: float, bucket_max: float,
+                     reg: float) -> torch.Tensor:
+    """Per-state critic loss (two-hot cross-entropy + reg * KL towards the slow critic), (rows,); gradient to
+    ``logits`` only."""
+    nb = logits.shape[-1]
+    slow2 = None if slow_logits is None else slow_logits.detach().reshape(-1, nb).float().contiguous()
+    return _CriticLossRowsFn.apply(logits.reshape(-1, nb).float().contiguous(), slow2,
+                                   returns.detach().reshape(-1).float().contiguous(), float(bucket_min), float(bucket_max), float(reg))
+
+
 def fused_ok(t: torch.Tensor, classes: int = 32) -> bool:
     return t.is_cuda and t.dtype == torch.float32 and classes == 32

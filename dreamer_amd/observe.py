@@ -144,13 +144,14 @@ class ObserveScanFn(torch.autograd.Function):
         gi2, gh2, dx2 = d_gi.reshape(B * T, -1), d_gh.reshape(B * T, -1), d_x.reshape(B * T, D)
         c2 = c_prev.reshape(B * T, 1)
         a2 = a_prev.reshape(B * T)
+        from .world_model import _mm_dgrad, _mm_wgrad
         z_in = F.one_hot(zidx_in.reshape(B * T, L).long(), K).to(h.dtype).reshape(B * T, LK)
         a_vec = a_emb[a2] * c2
-        g_w_ih = gi2.t() @ x.reshape(B * T, D)
-        g_w_hh = gh2.t() @ h_in.reshape(B * T, D)
-        g_lin_w = torch.cat([dx2.t() @ z_in, dx2.t() @ a_vec], dim=1)
-        g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, (dx2 @ lin_w[:, LK:]) * c2)
-        g_fc = d_post.reshape(B * T, LK).t() @ h.reshape(B * T, D)
+        g_w_ih = _mm_wgrad(gi2, x.reshape(B * T, D))
+        g_w_hh = _mm_wgrad(gh2, h_in.reshape(B * T, D))
+        g_lin_w = torch.cat([_mm_wgrad(dx2, z_in), _mm_wgrad(dx2, a_vec)], dim=1)
+        g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, _mm_dgrad(dx2, lin_w[:, LK:]) * c2)
+        g_fc = _mm_wgrad(d_post.reshape(B * T, LK), h.reshape(B * T, D))
         return (None, d_post.reshape(B, T, LK), g_a_emb, g_lin_w, dx2.sum(0), g_w_ih, g_w_hh, gi2.sum(0), gh2.sum(0), g_fc,
                 None, None, None, None, None, None)
 

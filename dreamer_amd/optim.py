@@ -71,6 +71,8 @@ class FlatAdam:
         listed = sum(len(grp["params"]) for grp in sd["param_groups"])
         if listed != n_all:
             raise ValueError(f"optimizer state lists {listed} parameters, the module has {n_all}")
+        if g.seen is None:
+            g.seen = set()      # from here on: the slots with state in the file, plus whatever receives a gradient later
         for slot, pid in enumerate(ids):
             st = sd["state"].get(pid)
             if st is None:
@@ -78,5 +80,4 @@ class FlatAdam:
             g.slot_view(self.exp_avg, slot).copy_(st["exp_avg"])
             g.slot_view(self.exp_avg_sq, slot).copy_(st["exp_avg_sq"])
             self.step_count.fill_(float(st["step"]))
-            if g.seen is not None:
-                g.seen.add(slot)
+            g.seen.add(slot)

@@ -399,7 +399,8 @@ def _rng_snapshot():
 
 def _rng_restore(snap) -> None:
     pos, has_gauss = (int(v) for v in snap["numpy_pos"])
-    np.random.set_state(("MT19937", snap["numpy_keys"].numpy().astype(np.uint32), pos, has_gauss, float(snap["numpy_gauss"][0])))
+    np.random.set_state(("MT19937", snap["numpy_keys"].cpu().numpy().astype(np.uint32), pos, has_gauss,
+                         float(snap["numpy_gauss"][0])))
     torch.set_rng_state(snap["torch_cpu"].cpu())
     if "torch_cuda" in snap and torch.cuda.is_available():
         torch.cuda.set_rng_state(snap["torch_cuda"].cpu())

@@ -33,15 +33,77 @@ class WorldModelState:
     z: torch.Tensor  # (B, L, K) one-hot, or (B, T, L, K)
 
 
+# From this many rows on, the Linear products of the batched (B*T)-row side of the update (forward, input gradient,
+# weight gradient) run on the library's fp32 MFMA kernel; below it the backend's routine serves the few rows.
+NATIVE_GEMM_MIN_ROWS = int(os.environ.get("DRM_NATIVE_GEMM_MIN_ROWS", "256"))
+
+
+def _mm_forward(x, w, b):
+    """x @ w.T + b for a Linear weight w (out, in)."""
+    from . import _native as N
+    if x.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(x, w, False, False):
+        return N.gemm(x, w, False, False, bias=b)
+    return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
+
+
+def _mm_dgrad(dy, w):
+    """dy @ w: the input gradient of a Linear with weight w (out, in)."""
+    from . import _native as N
+    if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, w, False, True):
+        return N.gemm(dy, w, False, True)
+    return dy @ w
+
+
+def _mm_wgrad(dy, x):
+    """dy.T @ x: the weight gradient of a Linear, a sum over the rows."""
+    from . import _native as N
+    if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, x, True, True):
+        return N.gemm(dy, x, True, True)
+    return dy.t() @ x
+
+
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear on (rows, in) inputs with the three products on the library's kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return _mm_forward(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _mm_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = _mm_wgrad(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def _linear(x, w, b=None):
+    """F.linear for 2-D inputs; many-row fp32 inputs on a HIP device take the library's products."""
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= NATIVE_GEMM_MIN_ROWS:
+        return _LinearFn.apply(x if x.stride(1) == 1 else x.contiguous(), w, b)
+    return F.linear(x, w, b)
+
+
+class _Linear(nn.Linear):
+    """nn.Linear (same parameters and state-dict keys) whose many-row GPU evaluations use ``_linear``."""
+
+    def forward(self, x):
+        return _linear(x, self.weight, self.bias) if x.dim() == 2 else super().forward(x)
+
+
 class _LinearNormActFn(torch.autograd.Function):
-    """nn.Linear -> nn.LayerNorm(width) -> nn.SiLU on (rows, in) inputs: the GEMMs stay torch's, the
-    normalisation + activation and their backward (with the Linear's bias gradient as a by-product of
-    the parameter-gradient pass) are the library's row kernels."""
+    """nn.Linear -> nn.LayerNorm(width) -> nn.SiLU on (rows, in) inputs: the normalisation + activation and
+    their backward (with the Linear's bias gradient as a by-product of the parameter-gradient pass) are the
+    library's row kernels, the three products its fp32 MFMA kernel (the backend's routine for few rows)."""
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, eps):
         from . import _native as N
-        pre = torch.addmm(b, x, w.t())
+        pre = _mm_forward(x, w, b)
         y, mean, rstd = N.ln_silu_forward(pre, gamma, beta, eps)
         ctx.save_for_backward(x, w, pre, gamma, beta, mean, rstd)
         return y
@@ -51,8 +113,8 @@ class _LinearNormActFn(torch.autograd.Function):
         from . import _native as N
         x, w, pre, gamma, beta, mean, rstd = ctx.saved_tensors
         dpre, dparams, db = N.ln_silu_backward(pre, dy.contiguous(), gamma, beta, mean, rstd, want_dx_sum=True)
-        dx = dpre @ w if ctx.needs_input_grad[0] else None
-        return dx, dpre.t() @ x, db, dparams[0], dparams[1], None
+        dx = _mm_dgrad(dpre, w) if ctx.needs_input_grad[0] else None
+        return dx, _mm_wgrad(dpre, x), db, dparams[0], dparams[1], None
 
 
 class _MLP(nn.Sequential):
@@ -83,7 +145,7 @@ def _norm_act_mlp(in_dim: int, width: int, depth: int) -> nn.Sequential:
     """depth x (Linear, LayerNorm, SiLU), laid out so that state-dict keys are mlp.{0,1,3,4,...}."""
     mods = []
     for i in range(depth):
-        mods += [nn.Linear(in_dim if i == 0 else width, width), nn.LayerNorm(width), nn.SiLU()]
+        mods += [_Linear(in_dim if i == 0 else width, width), nn.LayerNorm(width), nn.SiLU()]
     return _MLP(*mods)
 
 
@@ -279,7 +341,7 @@ class Encoder(nn.Module):
         sizes = [(H >> s, W >> s) for s in (1, 2, 3, 4)]
         self.conv = _Tower(*_conv_tower([C, c, 2 * c, 4 * c, 8 * c], sizes, False), nn.Flatten())
         self.conv_out_size = 8 * c * (H // 16) * (W // 16)
-        self.fc = nn.Sequential(nn.Linear(self.conv_out_size + hidden_size, num_latents * classes_per_latent))
+        self.fc = nn.Sequential(_Linear(self.conv_out_size + hidden_size, num_latents * classes_per_latent))
 
     def forward(self, x_t, h_t):
         B, C, H, W = x_t.shape
@@ -294,7 +356,7 @@ class DynamicsPredictor(nn.Module):
     def __init__(self, hidden_size=512, num_latents=32, classes_per_latent=32, mlp_hidden_units=512, mlp_layers=3):
         super().__init__()
         self.mlp = _norm_act_mlp(hidden_size, mlp_hidden_units, mlp_layers)
-        self.head = nn.Linear(mlp_hidden_units, num_latents * classes_per_latent)
+        self.head = _Linear(mlp_hidden_units, num_latents * classes_per_latent)
         self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
 
     def forward(self, h_t):
@@ -305,7 +367,7 @@ class _ScalarHead(nn.Module):
     def __init__(self, width_h, num_latents, classes_per_latent, mlp_hidden_units, mlp_layers):
         super().__init__()
         self.mlp = _norm_act_mlp(width_h + num_latents * classes_per_latent, mlp_hidden_units, mlp_layers)
-        self.head = nn.Linear(mlp_hidden_units, 1)
+        self.head = _Linear(mlp_hidden_units, 1)
         self.num_latents, self.classes_per_latent = num_latents, classes_per_latent
 
     def forward(self, h_t, z_t):
@@ -332,7 +394,7 @@ class Decoder(nn.Module):
         self.C, self.H, self.W = C, H, W
         self.base_h, self.base_w = H // 16, W // 16
         self.cnn_multiplier = c = base_cnn_channels
-        self.fc = nn.Sequential(nn.Linear(hidden_size + num_latents * classes_per_latent, 8 * c * self.base_h * self.base_w),
+        self.fc = nn.Sequential(_Linear(hidden_size + num_latents * classes_per_latent, 8 * c * self.base_h * self.base_w),
                                 nn.SiLU())
         sizes = [(self.base_h << s, self.base_w << s) for s in (1, 2, 3)]
         self.deconv = _Tower(*_conv_tower([8 * c, 4 * c, 2 * c, c], sizes, True),
@@ -463,7 +525,7 @@ class WorldModel(nn.Module):
         fc = self.enc.fc[0]
         n_conv = self.enc.conv_out_size
         feat = self.enc.conv(obs.reshape(B * T, *obs.shape[2:]))
-        e_part = F.linear(feat, fc.weight[:, :n_conv], fc.bias).view(B, T, L * K)
+        e_part = _linear(feat, fc.weight[:, :n_conv], fc.bias).view(B, T, L * K)
         return observe_scan(self, e_part, a_prev, c_prev, noise["reset"], noise["z"], state)
 
     def loss(self, obs, actions, rewards, continues, init_state: Optional[WorldModelState] = None,

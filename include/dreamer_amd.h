@@ -113,6 +113,29 @@ int drm_mse_rows_forward(const float* x_hat, const float* x, int64_t rows, int32
 int drm_mse_rows_backward(const float* x_hat, const float* x, int64_t rows, int32_t E, const float* g, float* d_x_hat,
                           drm_stream_t stream);
 
+/* Critic loss rows (lib/critic.py:140-161 with the two-hot target of lib/critic.py:103-129): for each of `rows`
+ * states, row_loss = -sum_k y_k log_softmax(logits)_k + reg * sum_k kl_div(log_softmax(logits), softmax(slow_logits))_k,
+ * y = two-hot encoding of clamp(symlog(returns), bucket_min, bucket_max) over NB <= 256 equally spaced buckets.
+ * logits, slow_logits: (rows, NB); returns, row_loss, g_rows: (rows).  reg <= 0: no regulariser (slow_logits unused).
+ * backward: d_logits = g_rows * ((softmax - y) + reg * (softmax - softmax(slow_logits))); no gradient to the others. */
+int drm_critic_loss_forward(const float* logits, const float* slow_logits, const float* returns, int64_t rows, int32_t NB,
+                            double bucket_min, double bucket_max, double reg, float* row_loss, drm_stream_t stream);
+int drm_critic_loss_backward(const float* logits, const float* slow_logits, const float* returns, const float* g_rows,
+                             int64_t rows, int32_t NB, double bucket_min, double bucket_max, double reg, float* d_logits,
+                             drm_stream_t stream);
+
+/* Critic.update_slow (lib/critic.py:131-138) over `count` tensors in one launch (per 32 tensors):
+ * dst[i] <- dst[i] * decay, then dst[i] <- dst[i] + src[i] * (1 - decay), each step rounded to fp32.
+ * src, dst, numel are HOST arrays of `count` device pointers / element counts. */
+int drm_ema_multi(int32_t count, const float* const* src, float* const* dst, const int64_t* numel, double decay,
+                  drm_stream_t stream);
+
+/* EMAPercentileScale.update_get_S (lib/actor.py:16-33) in one launch: the q_lo / q_hi quantiles of x (n <= 16384
+ * values, torch.quantile's linear interpolation), hi = max(hi, lo + 1e-8), when `training` the EMA update of the
+ * device scalars p_lo, p_hi (p <- p * decay + (1 - decay) * q), and scale_out[0] = max(p_hi - p_lo, limit). */
+int drm_percentile_scale(const float* x, int32_t n, double q_lo, double q_hi, double decay, double limit, int32_t training,
+                         float* p_lo, float* p_hi, float* scale_out, drm_stream_t stream);
+
 /* nn.ConvTranspose2d(Cin, Cout <= 4, kernel 4, stride 2, padding 1) + bias, forward: the last decoder stage
  * (lib/world_model.py:298-302).  x (N, Cin, H, W), weight (Cin, Cout, 4, 4) (torch's layout), bias (Cout) or
  * NULL, y (N, Cout, 2H, 2W); all contiguous fp32. */
@@ -166,6 +189,19 @@ int drm_fused_linear_bf16(const drm_linear_args* args, drm_stream_t stream);
  * below the rounding of an fp32 product).  Results agree with drm_fused_linear_f32 to fp32 rounding
  * (same nn.Linear semantics, lib/world_model.py:153-160).  No LayerNorm prologue; any M. */
 int drm_fused_linear_split(const drm_linear_args* args, drm_stream_t stream);
+
+/* ---- general fp32 product for the batched (B*T)-row Linear layers of the world-model update and their gradients
+ * (nn.Linear forward, lib/world_model.py:153-160, :203-217, :283-288 etc., and what autograd computes for it) ----
+ *   C (M, N) = op(A) . op(B) (+ bias[n]),  fp32 MFMA, fp32 accumulation
+ *   trans_a = 0: A is (M, K) with k contiguous;   trans_a = 1: A is (K, M) with m contiguous
+ *   trans_b = 0: B is (N, K) with k contiguous (torch Linear weight);   trans_b = 1: B is (K, N) with n contiguous
+ * forward Y = X W^T: (0, 0);  input gradient dX = dY W: (0, 1);  weight gradient dW = dY^T X: (1, 1).
+ * lda, ldb multiples of 4, A and B 16-byte aligned, K % 4 == 0 for a k-contiguous operand.  Small outputs split K
+ * over workgroups into `workspace` (drm_gemm_workspace_bytes, may be 0) and are summed in a fixed order. */
+size_t drm_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int drm_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda,
+                 const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, void* workspace,
+                 size_t workspace_bytes, drm_stream_t stream);
 
 /* ---- imagination block: lib/trainer.py:176-224 ----------------------------------------------
  * actor -> sample action -> WorldModel.step(prior) for H steps, then reward / continue heads,
