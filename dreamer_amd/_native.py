@@ -123,6 +123,10 @@ SIGNATURES = {
     "drm_percentile_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_convt_k4s2_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_conv4s2_down": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_conv4s2_up": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_conv4s2_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int32] * 4),
+    "drm_conv4s2_wgrad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_adam_workspace_bytes": (C.c_size_t, []),
     "drm_adam_flat_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 5 + [C.c_void_p] * 4),
     "drm_copy_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -412,6 +416,62 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
                              c.data_ptr(), c.stride(0), ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(a.device)),
           "drm_gemm_f32")
     return c
+
+
+def _cl4(x: torch.Tensor, name: str) -> torch.Tensor:
+    """A 4-D fp32 device tensor whose memory is channels-last (N, H, W, C) dense."""
+    if x.dim() != 4 or x.dtype != torch.float32 or not x.is_cuda:
+        raise NativeError(f"{name}: expected a 4-D fp32 device tensor")
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+def conv4s2_ok(cs: int, cb: int, mode: str) -> bool:
+    """Whether the implicit-product kernels take a layer with `cs` channels on its small-resolution side and `cb` on
+    its big-resolution side (mode: "down", "up" or "wgrad")."""
+    if cs % 4 or cb % 4:
+        return False
+    return {"down": cb % 32 == 0, "up": cs % 32 == 0, "wgrad": True}[mode]
+
+
+def conv4s2_down(big: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """conv2d(big, kernel, stride 2, padding 1) for kernel (cs, cb, 4, 4); channels-last in and out."""
+    big, kernel = _cl4(big, "big"), _cl4(kernel, "kernel")
+    ni, cb, hb, wb = big.shape
+    cs = kernel.shape[0]
+    out = torch.empty((ni, cs, hb // 2, wb // 2), dtype=torch.float32, device=big.device, memory_format=torch.channels_last)
+    check(lib().drm_conv4s2_down(big.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hb // 2, wb // 2, cs, cb,
+                                 stream_ptr(big.device)), "drm_conv4s2_down")
+    return out
+
+
+def conv4s2_up(small: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    """conv_transpose2d(small, kernel, stride 2, padding 1) for kernel (cs, cb, 4, 4); channels-last in and out."""
+    small, kernel = _cl4(small, "small"), _cl4(kernel, "kernel")
+    ni, cs, hs, ws = small.shape
+    cb = kernel.shape[1]
+    out = torch.empty((ni, cb, 2 * hs, 2 * ws), dtype=torch.float32, device=small.device, memory_format=torch.channels_last)
+    check(lib().drm_conv4s2_up(small.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, stream_ptr(small.device)),
+          "drm_conv4s2_up")
+    return out
+
+
+def conv4s2_wgrad(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
+    """Kernel gradient (cs, cb, 4, 4) (channels-last memory) of a stride-2 4x4 layer from its small- and big-resolution
+    tensors: for a convolution (big -> small) pass (grad_output, input), for a transposed one (input, grad_output)."""
+    small, big = _cl4(small, "small"), _cl4(big, "big")
+    ni, cs, hs, ws = small.shape
+    cb = big.shape[1]
+    out = torch.empty((cs, cb, 4, 4), dtype=torch.float32, device=small.device, memory_format=torch.channels_last)
+    need = lib().drm_conv4s2_wgrad_workspace_bytes(ni, hs, ws, cs, cb)
+    ws_t = None
+    if need:
+        held = _gemm_ws.setdefault(small.device, [])
+        if not held or held[-1].numel() * 4 < need:
+            held.append(torch.empty(need // 4 + 4, dtype=torch.float32, device=small.device))
+        ws_t = held[-1]
+    check(lib().drm_conv4s2_wgrad(small.data_ptr(), big.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, ptr(ws_t),
+                                  0 if ws_t is None else ws_t.numel() * 4, stream_ptr(small.device)), "drm_conv4s2_wgrad")
+    return out
 
 
 PERCENTILE_MAX = 16384

@@ -1,0 +1,338 @@
+// Stride-2 4x4 convolutions of the encoder / decoder towers (nn.Conv2d(k4, s2, p1), lib/world_model.py:94-108, and
+// nn.ConvTranspose2d(k4, s2, p1), lib/world_model.py:290-302) as implicit matrix products on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), activations in channels-last memory (N, H, W, C), no im2col buffer.
+//
+// One layer relates a big-resolution tensor T (NI, 2Hs, 2Ws, cb) and a small-resolution tensor S (NI, Hs, Ws, cs)
+// through a kernel Q stored [cs][kh][kw][cb]: nn.Conv2d maps T -> S (Q = weight (cs, cb, 4, 4) in channels-last
+// memory), nn.ConvTranspose2d maps S -> T (Q = weight (cs, cb, 4, 4) in channels-last memory as well: its first
+// dimension is the input = small-resolution side).  Pixel relation: big (y, x) meets small (a, b) through tap
+// (kh, kw) when y = 2a - 1 + kh, x = 2b - 1 + kw.  Three products cover forward and both gradients of both layers:
+//
+//   DOWN  S[m, j]        = sum_{kh,kw,c} T[pix(m; kh,kw), c] Q[j, kh, kw, c]        conv forward, convT input gradient
+//   UP    T[p, c]        = sum_{taps,s}  S[pix(p; tap), s]   Q[s, kh, kw, c]        convT forward, conv input gradient
+//                          (per parity class of p only 2 x 2 of the 16 taps meet a small pixel)
+//   WGRAD dQ[j, kh,kw,c] = sum_m         S[m, j] T[pix(m; kh,kw), c]                weight gradient of both
+//
+// Workgroup = 4 waves = 64 x 64 output tile (2 x 2 waves, one 32 x 32 accumulator each), reduction in steps of 32
+// through two LDS buffers with two register stages of global loads in flight.  Operands whose reduction index is
+// contiguous in memory are staged [row][k] (stride 36 words, 16-byte fragment reads), the others [k][row] (stride 68,
+// one word per lane and MFMA).  WGRAD splits its long reduction (all output pixels) over blockIdx.z into partial
+// tiles that a second kernel sums in a fixed order.
+#include "common.hpp"
+#include "../../include/dreamer_amd.h"
+
+namespace drm {
+
+constexpr int CV_BK = 32, CV_LDK = 36, CV_LDT = 68;
+constexpr int CV_STAGE_WORDS = 64 * CV_LDK;   // 2304 >= 32 * 68 = 2176
+static_assert(CV_STAGE_WORDS >= CV_BK * CV_LDT, "stage size");
+
+struct ConvArgs {
+    const float* T; const float* S; const float* Q;   // DOWN reads T, Q; UP reads S, Q; WGRAD reads S, T
+    float* out;                                        // DOWN: S-shaped; UP: T-shaped; WGRAD: Q-shaped (or partials)
+    int NI, Hs, Ws, cs, cb;
+    int ksteps_per_split;                              // WGRAD
+    float* partial;                                    // WGRAD with splits > 1: (splits, cs, 16 cb)
+};
+
+enum { CONV_DOWN = 0, CONV_UP = 1, CONV_WGRAD = 2 };
+
+__device__ __forceinline__ void st_rowk(float* buf, int tid, const float4 (&v)[2]) {
+    const int kq = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(buf + ((tid >> 3) + 32 * i) * CV_LDK + kq) = v[i];
+}
+__device__ __forceinline__ void st_krow(float* buf, int tid, const float4 (&v)[2]) {
+    const int r4 = (tid & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(buf + ((tid >> 4) + 16 * i) * CV_LDT + r4) = v[i];
+}
+__device__ __forceinline__ float4 fr_rowk(const float* buf, int row, int g, int lh) {
+    return *reinterpret_cast<const float4*>(buf + row * CV_LDK + g * 8 + lh * 4);
+}
+__device__ __forceinline__ float4 fr_krow(const float* buf, int row, int g, int lh) {
+    const float* p = buf + (g * 8 + lh * 4) * CV_LDT + row;
+    return make_float4(p[0], p[CV_LDT], p[2 * CV_LDT], p[3 * CV_LDT]);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_gemm(const ConvArgs G) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * CV_STAGE_WORDS];
+    float* sA[2] = {smem, smem + CV_STAGE_WORDS};
+    float* sB[2] = {smem + 2 * CV_STAGE_WORDS, smem + 3 * CV_STAGE_WORDS};
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1, li = lane & 31, lh = lane >> 5;
+    const int Hs = G.Hs, Ws = G.Ws, cs = G.cs, cb = G.cb, Hb = 2 * Hs, Wb = 2 * Ws;
+    const int pixels = G.NI * Hs * Ws;                 // small-resolution pixels
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+
+    // ---- per-thread row bookkeeping
+    // [row][k] staging: rows (tid >> 3) + 32 i; [k][row] staging: reduction rows (tid >> 4) + 16 i, columns (tid & 15) * 4
+    int pn[2] = {0, 0}, pa[2] = {0, 0}, pb[2] = {0, 0};   // image, small row, small column of the thread's two A rows
+    bool pv[2] = {false, false};
+    int py = 0, px = 0;
+    if (MODE == CONV_DOWN || MODE == CONV_UP) {
+        if (MODE == CONV_UP) { py = blockIdx.z >> 1; px = blockIdx.z & 1; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            pv[i] = m < pixels;
+            const int mm = pv[i] ? m : 0;
+            pn[i] = mm / (Hs * Ws);
+            const int r = mm - pn[i] * (Hs * Ws);
+            pa[i] = r / Ws;
+            pb[i] = r - pa[i] * Ws;
+        }
+    }
+    // WGRAD: the thread's 4 output columns (kh, kw, c) are fixed for the whole reduction
+    int w_kh = 0, w_kw = 0, w_c = 0;
+    bool w_nv = false;
+    if (MODE == CONV_WGRAD) {
+        const int col = n0 + (tid & 15) * 4;
+        w_nv = col < 16 * cb;
+        const int cell = (w_nv ? col : 0) / cb;
+        w_c = (w_nv ? col : 0) - cell * cb;
+        w_kh = cell >> 2; w_kw = cell & 3;
+    }
+
+    int nk, ks0 = 0;
+    if (MODE == CONV_DOWN) nk = 16 * cb / CV_BK;
+    else if (MODE == CONV_UP) nk = 4 * cs / CV_BK;
+    else {
+        const int nk_all = (pixels + CV_BK - 1) / CV_BK;
+        ks0 = blockIdx.z * G.ksteps_per_split;
+        nk = min(ks0 + G.ksteps_per_split, nk_all) - ks0;
+    }
+
+    auto load_a = [&](float4 (&v)[2], int ks) {
+        if (MODE == CONV_DOWN) {
+            // im2col row of T: the 32 k of this step lie inside one (kh, kw) cell (cb % 32 == 0)
+            const int k0 = ks * CV_BK, cell = k0 / cb, c0 = k0 - cell * cb + (tid & 7) * 4;
+            const int kh = cell >> 2, kw = cell & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int y = 2 * pa[i] - 1 + kh, x = 2 * pb[i] - 1 + kw;
+                const bool ok = pv[i] && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;
+                v[i] = ok ? *reinterpret_cast<const float4*>(G.T + ((int64_t)(pn[i] * Hb + y) * Wb + x) * cb + c0) : zero;
+            }
+        } else if (MODE == CONV_UP) {
+            // small-resolution pixel met through tap (th, tw) of this parity class (cs % 32 == 0: one tap per step)
+            const int k0 = ks * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs + (tid & 7) * 4;
+            const int th = tap >> 1, tw = tap & 1;
+            const int da = py ? (th ? 0 : 1) : (th ? -1 : 0), db = px ? (tw ? 0 : 1) : (tw ? -1 : 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int a = pa[i] + da, b = pb[i] + db;
+                const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;
+                v[i] = ok ? *reinterpret_cast<const float4*>(G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0) : zero;
+            }
+        } else {
+            // S as (pixels, cs): reduction row m, 4 consecutive output rows j
+            const int j = m0 + (tid & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = (ks0 + ks) * CV_BK + (tid >> 4) + 16 * i;
+                v[i] = (m < pixels && j < cs) ? *reinterpret_cast<const float4*>(G.S + (int64_t)m * cs + j) : zero;
+            }
+        }
+    };
+    auto load_b = [&](float4 (&v)[2], int ks) {
+        if (MODE == CONV_DOWN) {
+            const int k = ks * CV_BK + (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = n0 + (tid >> 3) + 32 * i;
+                v[i] = j < cs ? *reinterpret_cast<const float4*>(G.Q + (int64_t)j * 16 * cb + k) : zero;
+            }
+        } else if (MODE == CONV_UP) {
+            const int k0 = ks * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs;
+            const int th = tap >> 1, tw = tap & 1;
+            const int kh = py ? (th ? 2 : 0) : (th ? 3 : 1), kw = px ? (tw ? 2 : 0) : (tw ? 3 : 1);
+            const int c = n0 + (tid & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = s0 + (tid >> 4) + 16 * i;
+                v[i] = c < cb ? *reinterpret_cast<const float4*>(G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c) : zero;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = (ks0 + ks) * CV_BK + (tid >> 4) + 16 * i;
+                bool ok = w_nv && m < pixels;
+                const int mm = ok ? m : 0;
+                const int n = mm / (Hs * Ws), r = mm - n * (Hs * Ws), a = r / Ws, b = r - a * Ws;
+                const int y = 2 * a - 1 + w_kh, x = 2 * b - 1 + w_kw;
+                ok = ok && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;
+                v[i] = ok ? *reinterpret_cast<const float4*>(G.T + ((int64_t)(n * Hb + y) * Wb + x) * cb + w_c) : zero;
+            }
+        }
+    };
+    constexpr bool A_ROWK = MODE != CONV_WGRAD;     // DOWN / UP: A is [row][k]; WGRAD: A is [k][row]
+    constexpr bool B_ROWK = MODE == CONV_DOWN;      // DOWN: B = Q rows [j][k]; UP / WGRAD: [k][col]
+
+    float4 a0[2], a1[2], b0[2], b1[2];
+    a0[0] = a0[1] = a1[0] = a1[1] = b0[0] = b0[1] = b1[0] = b1[1] = zero;
+    if (nk > 0) { load_a(a0, 0); load_b(b0, 0); }
+    if (nk > 1) { load_a(a1, 1); load_b(b1, 1); }
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+#define CV_FA(buf, g) (A_ROWK ? fr_rowk(sA[buf], wm * 32 + li, g, lh) : fr_krow(sA[buf], wm * 32 + li, g, lh))
+#define CV_FB(buf, g) (B_ROWK ? fr_rowk(sB[buf], wn * 32 + li, g, lh) : fr_krow(sB[buf], wn * 32 + li, g, lh))
+#define CV_MMA4(fa, fb)                                                   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+#define CV_STEP(buf)                                            \
+    {                                                           \
+        float4 fa0 = CV_FA(buf, 0), fb0 = CV_FB(buf, 0);        \
+        float4 fa1 = CV_FA(buf, 1), fb1 = CV_FB(buf, 1);        \
+        CV_MMA4(fa0, fb0)                                       \
+        fa0 = CV_FA(buf, 2); fb0 = CV_FB(buf, 2);               \
+        CV_MMA4(fa1, fb1)                                       \
+        fa1 = CV_FA(buf, 3); fb1 = CV_FB(buf, 3);               \
+        CV_MMA4(fa0, fb0)                                       \
+        CV_MMA4(fa1, fb1)                                       \
+    }
+#define CV_STORE(av, bv, buf)                                   \
+    if (A_ROWK) st_rowk(sA[buf], tid, av); else st_krow(sA[buf], tid, av); \
+    if (B_ROWK) st_rowk(sB[buf], tid, bv); else st_krow(sB[buf], tid, bv);
+
+    for (int ks = 0; ks < nk; ks += 2) {
+        CV_STORE(a0, b0, 0)
+        __syncthreads();
+        if (ks + 2 < nk) { load_a(a0, ks + 2); load_b(b0, ks + 2); }
+        CV_STEP(0)
+        if (ks + 1 < nk) {
+            CV_STORE(a1, b1, 1)
+            __syncthreads();
+            if (ks + 3 < nk) { load_a(a1, ks + 3); load_b(b1, ks + 3); }
+            CV_STEP(1)
+        }
+    }
+#undef CV_FA
+#undef CV_FB
+#undef CV_MMA4
+#undef CV_STEP
+#undef CV_STORE
+
+    // ---- epilogue through LDS: every thread owns 4 consecutive columns of a row
+    __syncthreads();
+    float (*sC)[68] = reinterpret_cast<float (*)[68]>(smem);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 + li] = acc[i];
+    __syncthreads();
+    const int c4 = (tid & 15) * 4, col = n0 + c4;
+    const int ncols = MODE == CONV_DOWN ? cs : (MODE == CONV_UP ? cb : 16 * cb);
+    const int nrows = MODE == CONV_WGRAD ? cs : pixels;
+    if (col >= ncols) return;
+    for (int r = tid >> 4; r < 64; r += 16) {
+        const int m = m0 + r;
+        if (m >= nrows) break;
+        const float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        float* o;
+        if (MODE == CONV_DOWN) o = G.out + (int64_t)m * cs + col;
+        else if (MODE == CONV_UP) {
+            const int n = m / (Hs * Ws), rr = m - n * (Hs * Ws), a = rr / Ws, b = rr - a * Ws;
+            o = G.out + ((int64_t)(n * Hb + 2 * a + py) * Wb + 2 * b + px) * cb + col;
+        } else {
+            float* base = G.partial ? G.partial + (int64_t)blockIdx.z * cs * 16 * cb : G.out;
+            o = base + (int64_t)m * 16 * cb + col;
+        }
+        *reinterpret_cast<float4*>(o) = y;      // ncols % 4 == 0
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ partial, int splits, int64_t total4,
+                                                      float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        float4 s = reinterpret_cast<const float4*>(partial)[i];
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(partial)[(int64_t)z * total4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+
+static int wgrad_splits(int64_t pixels, int cs, int cb) {
+    const int64_t tiles = (int64_t)((cs + 63) / 64) * ((16 * cb + 63) / 64);
+    const int64_t nk = (pixels + CV_BK - 1) / CV_BK;
+    int s = 1;
+    while (tiles * s < 512 && s * 2 <= 64 && nk / (s * 2) >= 8) s *= 2;
+    return s;
+}
+
+}  // namespace drm
+
+using namespace drm;
+
+static int check_conv(const void* a, const void* b, const void* out, int64_t NI, int32_t Hs, int32_t Ws, int32_t cs, int32_t cb) {
+    DRM_REQUIRE(a && b && out, DRM_EINVAL, "null pointer");
+    DRM_REQUIRE(NI >= 1 && Hs >= 1 && Ws >= 1 && NI * Hs * Ws < (1ll << 31) / 4, DRM_EINVAL, "images=%lld, %d x %d", (long long)NI, Hs, Ws);
+    DRM_REQUIRE(cs >= 4 && cb >= 4 && cs % 4 == 0 && cb % 4 == 0, DRM_ENOTSUP, "channel counts %d, %d must be multiples of 4", cs, cb);
+    DRM_REQUIRE(aligned16(a) && aligned16(b) && aligned16(out), DRM_EINVAL, "tensors must be 16-byte aligned");
+    return DRM_OK;
+}
+
+extern "C" int drm_conv4s2_down(const float* big, const float* kernel, float* small_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                int32_t cs, int32_t cb, drm_stream_t stream) {
+    if (int rc = check_conv(big, kernel, small_out, NI, Hs, Ws, cs, cb)) return rc;
+    DRM_REQUIRE(cb % 32 == 0, DRM_ENOTSUP, "big-resolution channel count %d must be a multiple of 32", cb);
+    ConvArgs g{big, nullptr, kernel, small_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
+    const int64_t pixels = NI * Hs * Ws;
+    ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
+    k_conv_gemm<CONV_DOWN><<<dim3((cs + 63) / 64, (unsigned)((pixels + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream>>>(g);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* big_out, int64_t NI, int32_t Hs, int32_t Ws,
+                              int32_t cs, int32_t cb, drm_stream_t stream) {
+    if (int rc = check_conv(small, kernel, big_out, NI, Hs, Ws, cs, cb)) return rc;
+    DRM_REQUIRE(cs % 32 == 0, DRM_ENOTSUP, "small-resolution channel count %d must be a multiple of 32", cs);
+    ConvArgs g{nullptr, small, kernel, big_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
+    const int64_t pixels = NI * Hs * Ws;
+    ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
+    k_conv_gemm<CONV_UP><<<dim3((cb + 63) / 64, (unsigned)((pixels + 63) / 64), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    DRM_LAUNCH_CHECK();
+    return DRM_OK;
+}
+
+extern "C" size_t drm_conv4s2_wgrad_workspace_bytes(int64_t NI, int32_t Hs, int32_t Ws, int32_t cs, int32_t cb) {
+    if (NI < 1 || Hs < 1 || Ws < 1 || cs < 1 || cb < 1) return 0;
+    const int s = wgrad_splits(NI * Hs * Ws, cs, cb);
+    return s > 1 ? (size_t)s * cs * 16 * cb * sizeof(float) : 0;
+}
+
+extern "C" int drm_conv4s2_wgrad(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                 int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, drm_stream_t stream) {
+    if (int rc = check_conv(small, big, kernel_grad_out, NI, Hs, Ws, cs, cb)) return rc;
+    const int64_t pixels = NI * Hs * Ws;
+    const int splits = wgrad_splits(pixels, cs, cb);
+    const int nk = (int)((pixels + CV_BK - 1) / CV_BK);
+    ConvArgs g{big, small, nullptr, kernel_grad_out, (int)NI, Hs, Ws, cs, cb, (nk + splits - 1) / splits, nullptr};
+    if (splits > 1) {
+        const size_t need = (size_t)splits * cs * 16 * cb * sizeof(float);
+        DRM_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), DRM_EINVAL, "workspace too small: need %zu bytes", need);
+        g.partial = (float*)workspace;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope prof(PC_LINEAR_BIG, s, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
+        k_conv_gemm<CONV_WGRAD><<<dim3((16 * cb + 63) / 64, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
+        DRM_LAUNCH_CHECK();
+    }
+    if (splits > 1) {
+        const int64_t total4 = (int64_t)cs * 16 * cb / 4;
+        const int64_t blocks = (total4 + 255) / 256;
+        ProfScope prof(PC_ELEMENTWISE, s, (double)splits * total4 * 4, 16.0 * (splits + 1.0) * total4);
+        k_conv_reduce<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s>>>(g.partial, splits, total4, kernel_grad_out);
+        DRM_LAUNCH_CHECK();
+    }
+    return DRM_OK;
+}

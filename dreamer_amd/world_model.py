@@ -263,7 +263,58 @@ class _LayerNormSiLUFn(torch.autograd.Function):
         return dx, dparams[0].view_as(weight), dparams[1].view_as(bias), None, dcb
 
 
+class _Conv4s2Fn(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d (kernel 4, stride 2, padding 1, no bias) of the towers on the library's
+    implicit-product kernels: forward, input gradient and weight gradient, activations in channels-last memory.
+    ``up``: the transposed convolution (small -> big resolution); its weight (in, out, 4, 4) has the small-resolution
+    side first, as the convolution's (out, in, 4, 4) has, so both share the three kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, up):
+        from . import _native as N
+        ctx.save_for_backward(x, weight)
+        ctx.up = up
+        return N.conv4s2_up(x, weight) if up else N.conv4s2_down(x, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _native as N
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        if ctx.up:
+            if ctx.needs_input_grad[0]:
+                gx = N.conv4s2_down(g, weight)
+            if ctx.needs_input_grad[1]:
+                gw = N.conv4s2_wgrad(x, g)
+        else:
+            if ctx.needs_input_grad[0]:
+                gx = N.conv4s2_up(g, weight)
+            if ctx.needs_input_grad[1]:
+                gw = N.conv4s2_wgrad(g, x)
+        return gx, gw, None
+
+
+# the towers' stride-2 4x4 layers run on the library's kernels from this many images on (DRM_NO_NATIVE_CONV=1: never)
+NATIVE_CONV_MIN_IMAGES = 10 ** 9 if os.environ.get("DRM_NO_NATIVE_CONV", "0") == "1" else int(os.environ.get("DRM_NATIVE_CONV_MIN_IMAGES", "16"))
+
+
+def _native_conv_ok(mod, x) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] >= NATIVE_CONV_MIN_IMAGES):
+        return False
+    if not (tuple(mod.kernel_size) == (4, 4) and tuple(mod.stride) == (2, 2) and tuple(mod.padding) == (1, 1)
+            and tuple(mod.dilation) == (1, 1) and mod.groups == 1):
+        return False
+    up = isinstance(mod, nn.ConvTranspose2d)
+    if up and tuple(mod.output_padding) != (0, 0):
+        return False
+    from . import _native as N
+    cs, cb = mod.weight.shape[0], mod.weight.shape[1]      # small- and big-resolution channel counts, either module
+    return all(N.conv4s2_ok(cs, cb, m) for m in ("down", "up", "wgrad"))
+
+
 def _conv_no_bias(mod, x):
+    if _native_conv_ok(mod, x):
+        return _Conv4s2Fn.apply(x, mod.weight, isinstance(mod, nn.ConvTranspose2d))
     if isinstance(mod, nn.ConvTranspose2d):
         return F.conv_transpose2d(x, mod.weight, None, mod.stride, mod.padding, mod.output_padding, mod.groups, mod.dilation)
     return F.conv2d(x, mod.weight, None, mod.stride, mod.padding, mod.dilation, mod.groups)

@@ -142,6 +142,24 @@ int drm_percentile_scale(const float* x, int32_t n, double q_lo, double q_hi, do
 int drm_convt_k4s2_forward(const float* x, const float* weight, const float* bias, float* y, int64_t N, int32_t Cin,
                            int32_t Cout, int32_t H, int32_t W, drm_stream_t stream);
 
+/* ---- stride-2 4x4 convolutions of the towers as implicit fp32 MFMA products, channels-last activations ----------
+ * nn.Conv2d(cb -> cs, kernel 4, stride 2, padding 1) (lib/world_model.py:94-108) and nn.ConvTranspose2d(cs -> cb, kernel 4,
+ * stride 2, padding 1) (lib/world_model.py:290-302), without bias (the bias is applied by the fused LayerNorm + SiLU that
+ * follows).  `big` is (NI, 2 Hs, 2 Ws, cb), `small` is (NI, Hs, Ws, cs), both dense channels-last; `kernel` is
+ * [cs][4][4][cb]: the weight of either module, (cs, cb, 4, 4) in torch's shape, held in channels-last memory.
+ *   down : small = conv2d(big)                  conv forward; the input gradient of the transposed convolution
+ *   up   : big = conv_transpose2d(small)        transposed-conv forward; the input gradient of the convolution
+ *   wgrad: kernel gradient from one tensor of each resolution (weight gradient of either module)
+ * cs, cb multiples of 4; down needs cb % 32 == 0, up needs cs % 32 == 0.  wgrad sums over all NI Hs Ws pixels: the sum
+ * is split over workgroups into `workspace` (drm_conv4s2_wgrad_workspace_bytes) and added up in a fixed order. */
+int drm_conv4s2_down(const float* big, const float* kernel, float* small_out, int64_t NI, int32_t Hs, int32_t Ws, int32_t cs,
+                     int32_t cb, drm_stream_t stream);
+int drm_conv4s2_up(const float* small, const float* kernel, float* big_out, int64_t NI, int32_t Hs, int32_t Ws, int32_t cs,
+                   int32_t cb, drm_stream_t stream);
+size_t drm_conv4s2_wgrad_workspace_bytes(int64_t NI, int32_t Hs, int32_t Ws, int32_t cs, int32_t cb);
+int drm_conv4s2_wgrad(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
+                      int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, drm_stream_t stream);
+
 /* Optimiser step on flat buffers: global-norm clip (torch.nn.utils.clip_grad_norm_, coefficient
  * min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clip) followed by Adam without weight decay, the
  * arithmetic of torch's fused Adam (lib/trainer.py:95-103 creates the optimisers, :170-173, :231-235,
