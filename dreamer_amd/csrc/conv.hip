@@ -23,9 +23,8 @@
 
 namespace drm {
 
-constexpr int CV_BK = 32, CV_LDK = 36, CV_LDT = 68;
-constexpr int CV_STAGE_WORDS = 64 * CV_LDK;   // 2304 >= 32 * 68 = 2176
-static_assert(CV_STAGE_WORDS >= CV_BK * CV_LDT, "stage size");
+constexpr int CV_BK = 32, CV_LDK = 36;
+constexpr int cv_stage_words(int rb) { return 64 * rb * CV_LDK > CV_BK * (64 * rb + 4) ? 64 * rb * CV_LDK : CV_BK * (64 * rb + 4); }
 
 struct ConvArgs {
     const float* T; const float* S; const float* Q;   // DOWN reads T, Q; UP reads S, Q; WGRAD reads S, T
@@ -37,45 +36,62 @@ struct ConvArgs {
 
 enum { CONV_DOWN = 0, CONV_UP = 1, CONV_WGRAD = 2 };
 
-__device__ __forceinline__ void st_rowk(float* buf, int tid, const float4 (&v)[2]) {
+// An operand tile of R = 64 * RB rows (RB = 1 or 2) by 32 reduction steps; every thread moves 2 * RB f32x4.
+//   [row][k] image: rows (tid >> 3) + 32 i, k offset (tid & 7) * 4, row stride 36 words
+//   [k][row] image: reduction rows (tid >> 4) + 16 (i % 2), columns (tid & 15) * 4 + 64 (i / 2), row stride 64 RB + 4 words
+template <int RB>
+__device__ __forceinline__ void st_rowk(float* buf, int tid, const f32x4 (&v)[2 * RB]) {
     const int kq = (tid & 7) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(buf + ((tid >> 3) + 32 * i) * CV_LDK + kq) = v[i];
+    for (int i = 0; i < 2 * RB; ++i) *reinterpret_cast<f32x4*>(buf + ((tid >> 3) + 32 * i) * CV_LDK + kq) = v[i];
 }
-__device__ __forceinline__ void st_krow(float* buf, int tid, const float4 (&v)[2]) {
+template <int RB>
+__device__ __forceinline__ void st_krow(float* buf, int tid, const f32x4 (&v)[2 * RB]) {
     const int r4 = (tid & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(buf + ((tid >> 4) + 16 * i) * CV_LDT + r4) = v[i];
+    for (int i = 0; i < 2 * RB; ++i)
+        *reinterpret_cast<f32x4*>(buf + ((tid >> 4) + 16 * (i & 1)) * (64 * RB + 4) + r4 + 64 * (i >> 1)) = v[i];
 }
-__device__ __forceinline__ float4 fr_rowk(const float* buf, int row, int g, int lh) {
-    return *reinterpret_cast<const float4*>(buf + row * CV_LDK + g * 8 + lh * 4);
+__device__ __forceinline__ f32x4 fr_rowk(const float* buf, int row, int g, int lh) {
+    return *reinterpret_cast<const f32x4*>(buf + row * CV_LDK + g * 8 + lh * 4);
 }
-__device__ __forceinline__ float4 fr_krow(const float* buf, int row, int g, int lh) {
-    const float* p = buf + (g * 8 + lh * 4) * CV_LDT + row;
-    return make_float4(p[0], p[CV_LDT], p[2 * CV_LDT], p[3 * CV_LDT]);
+template <int RB>
+__device__ __forceinline__ f32x4 fr_krow(const float* buf, int row, int g, int lh) {
+    constexpr int LD = 64 * RB + 4;
+    const float* p = buf + (g * 8 + lh * 4) * LD + row;
+    return f32x4{p[0], p[LD], p[2 * LD], p[3 * LD]};
 }
 
-template <int MODE>
+// MT x NT: 32 x 32 accumulators per wave (rows x columns); WN: waves side by side along the columns (2: waves 2 x 2,
+// workgroup tile 64 MT x 64 NT; 1: waves 4 x 1, tile 128 MT x 32 NT, for outputs of 32 columns).  RA / RB: 64-row
+// blocks of the staged operand tiles (a 32-column B tile is staged as half of a 64-column image).
+template <int MODE, int MT, int NT, int WN = 2>
 __global__ __launch_bounds__(256) void k_conv_gemm(const ConvArgs G) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * CV_STAGE_WORDS];
-    float* sA[2] = {smem, smem + CV_STAGE_WORDS};
-    float* sB[2] = {smem + 2 * CV_STAGE_WORDS, smem + 3 * CV_STAGE_WORDS};
+    constexpr int BM = 32 * MT * (4 / WN), BN = 32 * NT * WN;
+    constexpr int RA = BM / 64, RB = BN >= 64 ? BN / 64 : 1;
+    constexpr int A_WORDS = cv_stage_words(RA), B_WORDS = cv_stage_words(RB);
+    constexpr int SMEM_WORDS = 2 * (A_WORDS + B_WORDS) > BM * (BN + 4) ? 2 * (A_WORDS + B_WORDS) : BM * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_WORDS];
+    float* sA[2] = {smem, smem + A_WORDS};
+    float* sB[2] = {smem + 2 * A_WORDS, smem + 2 * A_WORDS + B_WORDS};
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave & 1, wn = wave >> 1, li = lane & 31, lh = lane >> 5;
+    const int wm = WN == 2 ? (wave & 1) : wave, wn = WN == 2 ? (wave >> 1) : 0, li = lane & 31, lh = lane >> 5;
     const int Hs = G.Hs, Ws = G.Ws, cs = G.cs, cb = G.cb, Hb = 2 * Hs, Wb = 2 * Ws;
     const int pixels = G.NI * Hs * Ws;                 // small-resolution pixels
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
     // ---- per-thread row bookkeeping
     // [row][k] staging: rows (tid >> 3) + 32 i; [k][row] staging: reduction rows (tid >> 4) + 16 i, columns (tid & 15) * 4
-    int pn[2] = {0, 0}, pa[2] = {0, 0}, pb[2] = {0, 0};   // image, small row, small column of the thread's two A rows
-    bool pv[2] = {false, false};
+    int pn[2 * RA], pa[2 * RA], pb[2 * RA];   // image, small row, small column of the thread's A rows
+    bool pv[2 * RA];
+#pragma unroll
+    for (int i = 0; i < 2 * RA; ++i) { pn[i] = pa[i] = pb[i] = 0; pv[i] = false; }
     int py = 0, px = 0;
     if (MODE == CONV_DOWN || MODE == CONV_UP) {
         if (MODE == CONV_UP) { py = blockIdx.z >> 1; px = blockIdx.z & 1; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 * RA; ++i) {
             const int m = m0 + (tid >> 3) + 32 * i;
             pv[i] = m < pixels;
             const int mm = pv[i] ? m : 0;
@@ -86,14 +102,15 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const ConvArgs G) {
         }
     }
     // WGRAD: the thread's 4 output columns (kh, kw, c) are fixed for the whole reduction
-    int w_kh = 0, w_kw = 0, w_c = 0;
-    bool w_nv = false;
-    if (MODE == CONV_WGRAD) {
-        const int col = n0 + (tid & 15) * 4;
-        w_nv = col < 16 * cb;
-        const int cell = (w_nv ? col : 0) / cb;
-        w_c = (w_nv ? col : 0) - cell * cb;
-        w_kh = cell >> 2; w_kw = cell & 3;
+    int w_kh[RB], w_kw[RB], w_c[RB];
+    bool w_nv[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const int col = n0 + (tid & 15) * 4 + 64 * q;
+        w_nv[q] = MODE == CONV_WGRAD && col < 16 * cb;
+        const int cell = (w_nv[q] ? col : 0) / cb;
+        w_c[q] = (w_nv[q] ? col : 0) - cell * cb;
+        w_kh[q] = cell >> 2; w_kw[q] = cell & 3;
     }
 
     int nk, ks0 = 0;
@@ -105,135 +122,156 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const ConvArgs G) {
         nk = min(ks0 + G.ksteps_per_split, nk_all) - ks0;
     }
 
-    auto load_a = [&](float4 (&v)[2], int ks) {
-        if (MODE == CONV_DOWN) {
-            // im2col row of T: the 32 k of this step lie inside one (kh, kw) cell (cb % 32 == 0)
-            const int k0 = ks * CV_BK, cell = k0 / cb, c0 = k0 - cell * cb + (tid & 7) * 4;
-            const int kh = cell >> 2, kw = cell & 3;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int y = 2 * pa[i] - 1 + kh, x = 2 * pb[i] - 1 + kw;
-                const bool ok = pv[i] && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;
-                v[i] = ok ? *reinterpret_cast<const float4*>(G.T + ((int64_t)(pn[i] * Hb + y) * Wb + x) * cb + c0) : zero;
-            }
-        } else if (MODE == CONV_UP) {
-            // small-resolution pixel met through tap (th, tw) of this parity class (cs % 32 == 0: one tap per step)
-            const int k0 = ks * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs + (tid & 7) * 4;
-            const int th = tap >> 1, tw = tap & 1;
-            const int da = py ? (th ? 0 : 1) : (th ? -1 : 0), db = px ? (tw ? 0 : 1) : (tw ? -1 : 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int a = pa[i] + da, b = pb[i] + db;
-                const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;
-                v[i] = ok ? *reinterpret_cast<const float4*>(G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0) : zero;
-            }
-        } else {
-            // S as (pixels, cs): reduction row m, 4 consecutive output rows j
-            const int j = m0 + (tid & 15) * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = (ks0 + ks) * CV_BK + (tid >> 4) + 16 * i;
-                v[i] = (m < pixels && j < cs) ? *reinterpret_cast<const float4*>(G.S + (int64_t)m * cs + j) : zero;
-            }
-        }
-    };
-    auto load_b = [&](float4 (&v)[2], int ks) {
-        if (MODE == CONV_DOWN) {
-            const int k = ks * CV_BK + (tid & 7) * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int j = n0 + (tid >> 3) + 32 * i;
-                v[i] = j < cs ? *reinterpret_cast<const float4*>(G.Q + (int64_t)j * 16 * cb + k) : zero;
-            }
-        } else if (MODE == CONV_UP) {
-            const int k0 = ks * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs;
-            const int th = tap >> 1, tw = tap & 1;
-            const int kh = py ? (th ? 2 : 0) : (th ? 3 : 1), kw = px ? (tw ? 2 : 0) : (tw ? 3 : 1);
-            const int c = n0 + (tid & 15) * 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int s = s0 + (tid >> 4) + 16 * i;
-                v[i] = c < cb ? *reinterpret_cast<const float4*>(G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c) : zero;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = (ks0 + ks) * CV_BK + (tid >> 4) + 16 * i;
-                bool ok = w_nv && m < pixels;
-                const int mm = ok ? m : 0;
-                const int n = mm / (Hs * Ws), r = mm - n * (Hs * Ws), a = r / Ws, b = r - a * Ws;
-                const int y = 2 * a - 1 + w_kh, x = 2 * b - 1 + w_kw;
-                ok = ok && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;
-                v[i] = ok ? *reinterpret_cast<const float4*>(G.T + ((int64_t)(n * Hb + y) * Wb + x) * cb + w_c) : zero;
-            }
-        }
-    };
+    // one f32x4 of an operand tile per call; the callers' loops are fully unrolled so that the staging arrays stay in
+    // registers (a lambda capturing them by reference makes them addressable, and they end up in scratch memory)
+#define CV_LOAD_A(v, ks_)                                                                                                \
+    {                                                                                                                    \
+        const int kst = (ks_);                                                                                            \
+        if (MODE == CONV_DOWN) {                                                                                         \
+            /* im2col row of T: the 32 k of this step lie inside one (kh, kw) cell (cb % 32 == 0) */                    \
+            const int k0 = kst * CV_BK, cell = k0 / cb, c0 = k0 - cell * cb + (tid & 7) * 4;                              \
+            const int kh = cell >> 2, kw = cell & 3;                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 2 * RA; ++i) {                                                         \
+                const int y = 2 * pa[i] - 1 + kh, x = 2 * pb[i] - 1 + kw;                                                \
+                const bool ok = pv[i] && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;                       \
+                v[i] = ok ? *reinterpret_cast<const f32x4*>(G.T + ((int64_t)(pn[i] * Hb + y) * Wb + x) * cb + c0) : zero; \
+            }                                                                                                            \
+        } else if (MODE == CONV_UP) {                                                                                    \
+            /* small-resolution pixel met through tap (th, tw) of this parity class (cs % 32 == 0: one tap per step) */ \
+            const int k0 = kst * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs + (tid & 7) * 4;                                \
+            const int th = tap >> 1, tw = tap & 1;                                                                       \
+            const int da = py ? (th ? 0 : 1) : (th ? -1 : 0), db = px ? (tw ? 0 : 1) : (tw ? -1 : 0);                    \
+            _Pragma("unroll") for (int i = 0; i < 2 * RA; ++i) {                                                         \
+                const int a = pa[i] + da, b = pb[i] + db;                                                                \
+                const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;                       \
+                v[i] = ok ? *reinterpret_cast<const f32x4*>(G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0) : zero; \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            /* S as (pixels, cs): reduction row m, 4 consecutive output rows j */                                        \
+            _Pragma("unroll") for (int i = 0; i < 2 * RA; ++i) {                                                         \
+                const int j = m0 + (tid & 15) * 4 + 64 * (i >> 1);                                                       \
+                const int m = (ks0 + kst) * CV_BK + (tid >> 4) + 16 * (i & 1);                                            \
+                v[i] = (m < pixels && j < cs) ? *reinterpret_cast<const f32x4*>(G.S + (int64_t)m * cs + j) : zero;      \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+#define CV_LOAD_B(v, ks_)                                                                                                \
+    {                                                                                                                    \
+        const int kst = (ks_);                                                                                            \
+        if (MODE == CONV_DOWN) {                                                                                         \
+            const int k = kst * CV_BK + (tid & 7) * 4;                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2 * RB; ++i) {                                                         \
+                const int j = n0 + (tid >> 3) + 32 * i;                                                                  \
+                v[i] = j < cs ? *reinterpret_cast<const f32x4*>(G.Q + (int64_t)j * 16 * cb + k) : zero;                 \
+            }                                                                                                            \
+        } else if (MODE == CONV_UP) {                                                                                    \
+            const int k0 = kst * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs;                                                \
+            const int th = tap >> 1, tw = tap & 1;                                                                       \
+            const int kh = py ? (th ? 2 : 0) : (th ? 3 : 1), kw = px ? (tw ? 2 : 0) : (tw ? 3 : 1);                      \
+            _Pragma("unroll") for (int i = 0; i < 2 * RB; ++i) {                                                         \
+                const int c = n0 + (tid & 15) * 4 + 64 * (i >> 1);                                                       \
+                const int s = s0 + (tid >> 4) + 16 * (i & 1);                                                            \
+                v[i] = c < cb ? *reinterpret_cast<const f32x4*>(G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c) : zero; \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                              \
+                const int m = (ks0 + kst) * CV_BK + (tid >> 4) + 16 * i;                                                  \
+                const bool in = m < pixels;                                                                              \
+                const int mm = in ? m : 0;                                                                               \
+                const int n = mm / (Hs * Ws), r = mm - n * (Hs * Ws), a = r / Ws, b = r - a * Ws;                        \
+                _Pragma("unroll") for (int q = 0; q < RB; ++q) {                                                         \
+                    const int y = 2 * a - 1 + w_kh[q], x = 2 * b - 1 + w_kw[q];                                          \
+                    const bool ok = in && w_nv[q] && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;           \
+                    v[i + 2 * q] = ok ? *reinterpret_cast<const f32x4*>(G.T + ((int64_t)(n * Hb + y) * Wb + x) * cb + w_c[q]) : zero; \
+                }                                                                                                        \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
     constexpr bool A_ROWK = MODE != CONV_WGRAD;     // DOWN / UP: A is [row][k]; WGRAD: A is [k][row]
     constexpr bool B_ROWK = MODE == CONV_DOWN;      // DOWN: B = Q rows [j][k]; UP / WGRAD: [k][col]
 
-    float4 a0[2], a1[2], b0[2], b1[2];
-    a0[0] = a0[1] = a1[0] = a1[1] = b0[0] = b0[1] = b1[0] = b1[1] = zero;
-    if (nk > 0) { load_a(a0, 0); load_b(b0, 0); }
-    if (nk > 1) { load_a(a1, 1); load_b(b1, 1); }
-
-    f32x16 acc;
+    f32x4 a0[2 * RA], a1[2 * RA], b0[2 * RB], b1[2 * RB];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 2 * RA; ++i) a0[i] = a1[i] = zero;
+#pragma unroll
+    for (int i = 0; i < 2 * RB; ++i) b0[i] = b1[i] = zero;
+    if (nk > 0) { CV_LOAD_A(a0, 0) CV_LOAD_B(b0, 0) }
+    if (nk > 1) { CV_LOAD_A(a1, 1) CV_LOAD_B(b1, 1) }
 
-#define CV_FA(buf, g) (A_ROWK ? fr_rowk(sA[buf], wm * 32 + li, g, lh) : fr_krow(sA[buf], wm * 32 + li, g, lh))
-#define CV_FB(buf, g) (B_ROWK ? fr_rowk(sB[buf], wn * 32 + li, g, lh) : fr_krow(sB[buf], wn * 32 + li, g, lh))
-#define CV_MMA4(fa, fb)                                                   \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
-#define CV_STEP(buf)                                            \
-    {                                                           \
-        float4 fa0 = CV_FA(buf, 0), fb0 = CV_FB(buf, 0);        \
-        float4 fa1 = CV_FA(buf, 1), fb1 = CV_FB(buf, 1);        \
-        CV_MMA4(fa0, fb0)                                       \
-        fa0 = CV_FA(buf, 2); fb0 = CV_FB(buf, 2);               \
-        CV_MMA4(fa1, fb1)                                       \
-        fa1 = CV_FA(buf, 3); fb1 = CV_FB(buf, 3);               \
-        CV_MMA4(fa0, fb0)                                       \
-        CV_MMA4(fa1, fb1)                                       \
+    f32x16 acc[MT * NT];
+#pragma unroll
+    for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // one K-step: four groups of 8 k; the fragments of group g + 1 are read before the MFMAs of group g
+    // (macros, not lambdas: accumulators captured by reference end up in scratch memory)
+#define CV_FRAGS(buf, g, fa, fb)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                       \
+        fa[i] = A_ROWK ? fr_rowk(sA[buf], wm * 32 * MT + 32 * i + li, g, lh) : fr_krow<RA>(sA[buf], wm * 32 * MT + 32 * i + li, g, lh); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                       \
+        fb[j] = B_ROWK ? fr_rowk(sB[buf], wn * 32 * NT + 32 * j + li, g, lh) : fr_krow<RB>(sB[buf], wn * 32 * NT + 32 * j + li, g, lh);
+#define CV_MMA1(fa, fb, c)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                       \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
+            acc[i * NT + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].c, fb[j].c, acc[i * NT + j], 0, 0, 0);
+#define CV_MMA(fa, fb) CV_MMA1(fa, fb, x) CV_MMA1(fa, fb, y) CV_MMA1(fa, fb, z) CV_MMA1(fa, fb, w)
+#define CV_STEP(buf)                                   \
+    {                                                  \
+        f32x4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];     \
+        CV_FRAGS(buf, 0, fa0, fb0)                     \
+        CV_FRAGS(buf, 1, fa1, fb1)                     \
+        CV_MMA(fa0, fb0)                               \
+        CV_FRAGS(buf, 2, fa0, fb0)                     \
+        CV_MMA(fa1, fb1)                               \
+        CV_FRAGS(buf, 3, fa1, fb1)                     \
+        CV_MMA(fa0, fb0)                               \
+        CV_MMA(fa1, fb1)                               \
     }
-#define CV_STORE(av, bv, buf)                                   \
-    if (A_ROWK) st_rowk(sA[buf], tid, av); else st_krow(sA[buf], tid, av); \
-    if (B_ROWK) st_rowk(sB[buf], tid, bv); else st_krow(sB[buf], tid, bv);
+#define CV_STAGE(av, bv, buf)                                                             \
+    if (A_ROWK) st_rowk<RA>(sA[buf], tid, av); else st_krow<RA>(sA[buf], tid, av);        \
+    if (B_ROWK) st_rowk<RB>(sB[buf], tid, bv); else st_krow<RB>(sB[buf], tid, bv);
 
     for (int ks = 0; ks < nk; ks += 2) {
-        CV_STORE(a0, b0, 0)
+        CV_STAGE(a0, b0, 0)
         __syncthreads();
-        if (ks + 2 < nk) { load_a(a0, ks + 2); load_b(b0, ks + 2); }
+        if (ks + 2 < nk) { CV_LOAD_A(a0, ks + 2) CV_LOAD_B(b0, ks + 2) }
         CV_STEP(0)
         if (ks + 1 < nk) {
-            CV_STORE(a1, b1, 1)
+            CV_STAGE(a1, b1, 1)
             __syncthreads();
-            if (ks + 3 < nk) { load_a(a1, ks + 3); load_b(b1, ks + 3); }
+            if (ks + 3 < nk) { CV_LOAD_A(a1, ks + 3) CV_LOAD_B(b1, ks + 3) }
             CV_STEP(1)
         }
     }
-#undef CV_FA
-#undef CV_FB
-#undef CV_MMA4
+#undef CV_LOAD_A
+#undef CV_LOAD_B
+#undef CV_FRAGS
+#undef CV_MMA1
+#undef CV_MMA
 #undef CV_STEP
-#undef CV_STORE
+#undef CV_STAGE
 
     // ---- epilogue through LDS: every thread owns 4 consecutive columns of a row
     __syncthreads();
-    float (*sC)[68] = reinterpret_cast<float (*)[68]>(smem);
+    float (*sC)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 + li] = acc[i];
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                sC[wm * 32 * MT + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh][wn * 32 * NT + 32 * j + li] = acc[i * NT + j][e];
     __syncthreads();
-    const int c4 = (tid & 15) * 4, col = n0 + c4;
+    constexpr int TPR = BN / 4;                 // threads per output row
+    const int c4 = (tid % TPR) * 4, col = n0 + c4;
     const int ncols = MODE == CONV_DOWN ? cs : (MODE == CONV_UP ? cb : 16 * cb);
     const int nrows = MODE == CONV_WGRAD ? cs : pixels;
     if (col >= ncols) return;
-    for (int r = tid >> 4; r < 64; r += 16) {
+    for (int r = tid / TPR; r < BM; r += 256 / TPR) {
         const int m = m0 + r;
         if (m >= nrows) break;
-        const float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(&sC[r][c4]);
         float* o;
         if (MODE == CONV_DOWN) o = G.out + (int64_t)m * cs + col;
         else if (MODE == CONV_UP) {
@@ -243,24 +281,24 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const ConvArgs G) {
             float* base = G.partial ? G.partial + (int64_t)blockIdx.z * cs * 16 * cb : G.out;
             o = base + (int64_t)m * 16 * cb + col;
         }
-        *reinterpret_cast<float4*>(o) = y;      // ncols % 4 == 0
+        *reinterpret_cast<f32x4*>(o) = y;      // ncols % 4 == 0
     }
 }
 
 __global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ partial, int splits, int64_t total4,
                                                       float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        float4 s = reinterpret_cast<const float4*>(partial)[i];
+        f32x4 s = reinterpret_cast<const f32x4*>(partial)[i];
         for (int z = 1; z < splits; ++z) {
-            const float4 v = reinterpret_cast<const float4*>(partial)[(int64_t)z * total4 + i];
+            const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(int64_t)z * total4 + i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        reinterpret_cast<float4*>(out)[i] = s;
+        reinterpret_cast<f32x4*>(out)[i] = s;
     }
 }
 
 static int wgrad_splits(int64_t pixels, int cs, int cb) {
-    const int64_t tiles = (int64_t)((cs + 63) / 64) * ((16 * cb + 63) / 64);
+    const int64_t tiles = (int64_t)((cs + 63) / 64) * ((16 * cb + 127) / 128);
     const int64_t nk = (pixels + CV_BK - 1) / CV_BK;
     int s = 1;
     while (tiles * s < 512 && s * 2 <= 64 && nk / (s * 2) >= 8) s *= 2;
@@ -286,7 +324,7 @@ extern "C" int drm_conv4s2_down(const float* big, const float* kernel, float* sm
     ConvArgs g{big, nullptr, kernel, small_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-    k_conv_gemm<CONV_DOWN><<<dim3((cs + 63) / 64, (unsigned)((pixels + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream>>>(g);
+    k_conv_gemm<CONV_DOWN, 2, 1><<<dim3((cs + 63) / 64, (unsigned)((pixels + 127) / 128), 1), dim3(256), 0, (hipStream_t)stream>>>(g);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -298,7 +336,10 @@ extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* bi
     ConvArgs g{nullptr, small, kernel, big_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-    k_conv_gemm<CONV_UP><<<dim3((cb + 63) / 64, (unsigned)((pixels + 63) / 64), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    if (cb <= 32)   // outputs of 32 columns: waves 4 x 1 over a 256 x 32 tile instead of half-empty 64-column tiles
+        k_conv_gemm<CONV_UP, 2, 1, 1><<<dim3(1, (unsigned)((pixels + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    else
+        k_conv_gemm<CONV_UP, 2, 1><<<dim3((cb + 63) / 64, (unsigned)((pixels + 127) / 128), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -324,7 +365,7 @@ extern "C" int drm_conv4s2_wgrad(const float* small, const float* big, float* ke
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(PC_LINEAR_BIG, s, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-        k_conv_gemm<CONV_WGRAD><<<dim3((16 * cb + 63) / 64, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
+        k_conv_gemm<CONV_WGRAD, 1, 2><<<dim3((16 * cb + 127) / 128, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
         DRM_LAUNCH_CHECK();
     }
     if (splits > 1) {

@@ -36,22 +36,22 @@ struct GemmArgs {
 
 template <bool T>
 struct Stage {
-    // global -> registers: two float4 per thread per operand and K-step
-    float4 v[2];
+    // global -> registers: two f32x4 per thread per operand and K-step
+    f32x4 v[2];
 };
 
 // loads one 64-row x 32-k operand tile slice for this thread
 template <bool T>
 __device__ __forceinline__ void gm_load(Stage<T>& s, const float* __restrict__ P, int64_t ld, int row0, int rows, int k0, int K,
                                         int tid) {
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (!T) {
         // [row][k]: 8 threads cover the 32 k of a row; rows tid>>3 and (tid>>3) + 32
         const int kq = (tid & 7) * 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = row0 + (tid >> 3) + 32 * i;
-            s.v[i] = (r < rows && k0 + kq < K) ? *reinterpret_cast<const float4*>(P + (int64_t)r * ld + k0 + kq) : zero;
+            s.v[i] = (r < rows && k0 + kq < K) ? *reinterpret_cast<const f32x4*>(P + (int64_t)r * ld + k0 + kq) : zero;
         }
     } else {
         // [k][row]: 16 threads cover the 64 rows of one k; k = tid>>4 and (tid>>4) + 16
@@ -61,10 +61,10 @@ __device__ __forceinline__ void gm_load(Stage<T>& s, const float* __restrict__ P
             const int k = k0 + (tid >> 4) + 16 * i;
             const int r = row0 + r4;
             if (k < K && r + 3 < rows) {
-                s.v[i] = *reinterpret_cast<const float4*>(P + (int64_t)k * ld + r);
+                s.v[i] = *reinterpret_cast<const f32x4*>(P + (int64_t)k * ld + r);
             } else if (k < K && r < rows) {
                 const float* p = P + (int64_t)k * ld + r;
-                s.v[i] = make_float4(p[0], r + 1 < rows ? p[1] : 0.f, r + 2 < rows ? p[2] : 0.f, 0.f);
+                s.v[i] = f32x4{p[0], r + 1 < rows ? p[1] : 0.f, r + 2 < rows ? p[2] : 0.f, 0.f};
             } else {
                 s.v[i] = zero;
             }
@@ -77,22 +77,22 @@ __device__ __forceinline__ void gm_store(const Stage<T>& s, float* __restrict__ 
     if constexpr (!T) {
         const int kq = (tid & 7) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(buf + ((tid >> 3) + 32 * i) * GM_LDK + kq) = s.v[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(buf + ((tid >> 3) + 32 * i) * GM_LDK + kq) = s.v[i];
     } else {
         const int r4 = (tid & 15) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(buf + ((tid >> 4) + 16 * i) * GM_LDT + r4) = s.v[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(buf + ((tid >> 4) + 16 * i) * GM_LDT + r4) = s.v[i];
     }
 }
 
 // fragment of group g (k = g*8 + lh*4 + s, s = 0..3) for the row `row` of a 64-row operand tile
 template <bool T>
-__device__ __forceinline__ float4 gm_frag(const float* __restrict__ buf, int row, int g, int lh) {
+__device__ __forceinline__ f32x4 gm_frag(const float* __restrict__ buf, int row, int g, int lh) {
     if constexpr (!T) {
-        return *reinterpret_cast<const float4*>(buf + row * GM_LDK + g * 8 + lh * 4);
+        return *reinterpret_cast<const f32x4*>(buf + row * GM_LDK + g * 8 + lh * 4);
     } else {
         const float* p = buf + (g * 8 + lh * 4) * GM_LDT + row;
-        return make_float4(p[0], p[GM_LDT], p[2 * GM_LDT], p[3 * GM_LDT]);
+        return f32x4{p[0], p[GM_LDT], p[2 * GM_LDT], p[3 * GM_LDT]};
     }
 }
 
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
 
     Stage<TA> a0, a1;
     Stage<TB> b0, b1;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     a1.v[0] = a1.v[1] = b1.v[0] = b1.v[1] = zero;
     a0.v[0] = a0.v[1] = b0.v[0] = b0.v[1] = zero;
     if (nk > 0) { gm_load<TA>(a0, G.A, G.lda, m0, G.M, ks0 * GM_BK, G.K, tid); gm_load<TB>(b0, G.B, G.ldb, n0, G.N, ks0 * GM_BK, G.K, tid); }
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
 
 #define GM_STEP(buf)                                                                                  \
     {                                                                                                 \
-        float4 fa0 = gm_frag<TA>(sA[buf], wm * 32 + li, 0, lh), fb0 = gm_frag<TB>(sB[buf], wn * 32 + li, 0, lh); \
-        float4 fa1 = gm_frag<TA>(sA[buf], wm * 32 + li, 1, lh), fb1 = gm_frag<TB>(sB[buf], wn * 32 + li, 1, lh); \
+        f32x4 fa0 = gm_frag<TA>(sA[buf], wm * 32 + li, 0, lh), fb0 = gm_frag<TB>(sB[buf], wn * 32 + li, 0, lh); \
+        f32x4 fa1 = gm_frag<TA>(sA[buf], wm * 32 + li, 1, lh), fb1 = gm_frag<TB>(sB[buf], wn * 32 + li, 1, lh); \
         _Pragma("unroll") for (int g = 0; g < 4; g += 2) {                                            \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.x, fb0.x, acc, 0, 0, 0);                   \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.y, fb0.y, acc, 0, 0, 0);                   \
@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
     for (int r = tid >> 4; r < GM_BM; r += 16) {
         const int m = m0 + r;
         if (m >= G.M) break;
-        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
+        f32x4 y = *reinterpret_cast<const f32x4*>(&sC[r][c4]);
         y.x += bias[0]; y.y += bias[1]; y.z += bias[2]; y.w += bias[3];
         float* o = out + (int64_t)m * ldo + n;
-        if (vec) *reinterpret_cast<float4*>(o) = y;
+        if (vec) *reinterpret_cast<f32x4*>(o) = y;
         else { o[0] = y.x; if (n + 1 < G.N) o[1] = y.y; if (n + 2 < G.N) o[2] = y.z; if (n + 3 < G.N) o[3] = y.w; }
     }
 }
