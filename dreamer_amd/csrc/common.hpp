@@ -54,7 +54,7 @@ static __device__ unsigned long long* g_stamp_buf = nullptr;   // per translatio
 #define STAMP_DECL STAMP_DECL_AT(blockIdx.x == 0 && blockIdx.y == 0)
 #define STAMP() do { if (_stamper && _sn < 6) _st[_sn++] = wall_clock64(); } while (0)
 #define STAMP_FLUSH(kid) do { if (_stamper && g_stamp_buf) { unsigned long long r = atomicAdd(&g_stamp_buf[0], 1ull); \
-        if (r < 100000) { unsigned long long* o = g_stamp_buf + 1 + r * 8; o[0] = (kid); o[1] = _sn | ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 8); for (int i = 0; i < 6; ++i) o[2 + i] = i < _sn ? _st[i] : 0; } } } while (0)
+        if (r < 100000) { unsigned long long* o = g_stamp_buf + 1 + r * 8; o[0] = (kid); o[1] = _sn | ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 8) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 16) | ((unsigned long long)blockIdx.y << 48); for (int i = 0; i < 6; ++i) o[2 + i] = i < _sn ? _st[i] : 0; } } } while (0)
 #else
 #define STAMP_DECL_AT(cond)
 #define STAMP_DECL

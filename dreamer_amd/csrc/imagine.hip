@@ -673,6 +673,18 @@ static const uint16_t* split_planes_of(const ProblemSpec& q, hipStream_t stream)
     return planes;
 }
 
+// compute units of the current device (looked up once per device)
+static int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                hipStream_t stream, int precision) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
@@ -711,8 +723,18 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
     else if (precision == 2 && presplit) k_linear_big_split<true, 2><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2 && narrow) k_linear_big_split<false, 1><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2) k_linear_big_split<false, 2><<<grid, dim3(256), 0, stream>>>(L);
-    else if (narrow) k_linear_big64<<<grid, dim3(256), 0, stream>>>(L);
-    else k_linear_big<<<grid, dim3(256), 0, stream>>>(L);
+    else {
+        // fp32 form: a workgroup walks several tiles when no problem needs the epilogue through LDS and every K is an
+        // even number (>= 4) of 32-deep steps; the grid is then what is resident at once
+        L.ntx = (int)grid.x; L.nty = (int)grid.y;
+        const int64_t ntiles = (int64_t)grid.x * grid.y;
+        bool walk = std::getenv("DRM_NO_TILE_WALK") == nullptr;
+        for (int i = 0; i < np; ++i) walk = walk && specs[i].tab == nullptr && (specs[i].K / BIG_BK) % 2 == 0 && specs[i].K / BIG_BK >= 4;
+        const int64_t resident = (int64_t)cu_count() * (narrow ? 4 : 2);
+        const unsigned g = (unsigned)(walk && ntiles > resident ? resident : ntiles);
+        if (narrow) k_linear_big<1><<<dim3(g), dim3(256), 0, stream>>>(L);
+        else k_linear_big<2><<<dim3(g), dim3(256), 0, stream>>>(L);
+    }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

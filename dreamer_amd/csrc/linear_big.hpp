@@ -3,8 +3,7 @@
 //
 // Workgroup = 4 waves = a 64-row x 128-column output tile; waves are laid out 2 (rows) x 2 (columns),
 // each owning a 32 x 64 sub-tile = two 32x32 accumulators.  K is walked in steps of 32 through two LDS
-// buffers: while the MFMAs of step i run from one buffer, the global loads of step i+1 are in flight
-// into registers and are written to the other buffer afterwards (one barrier per step).
+// buffers with two register stages of global loads in flight (one barrier per step; schedule at k_linear_big).
 //
 // LDS image: [row][k] with a row stride of 36 words for both operands (X rows and W rows are both
 // K-contiguous in memory, so the same 128-byte-per-row coalesced load shape fills both).  A lane reads
@@ -34,128 +33,18 @@ struct BigLaunch {
     BigProblem p[4];
     int np, M;
     const uint8_t* zidx; int64_t ldz; int latents, classes;
+    int ntx = 0, nty = 0;            // fp32 form: column tiles (all problems) and row tiles; its grid is one-dimensional
 };
 
-constexpr int BIG_BM = 64, BIG_BN = 128, BIG_BK = 32, BIG_LD = 36;
+constexpr int BIG_BM = 64, BIG_BN = 128, BIG_BN64 = 64, BIG_BK = 32, BIG_LD = 36;
 
-// One K-step (32 deep) of a wave's 32 x 64 sub-tile: 4 groups of 8 MFMAs.  The LDS reads of group
-// g+1 are issued before the MFMAs of group g, so they complete under them.
-#define BIG_FRAG(buf, g, A, B0, B1)                                                                   \
-    A = *reinterpret_cast<const float4*>(&sA[buf][wm * 32 + li][(g) * 8 + lh * 4]);                  \
-    B0 = *reinterpret_cast<const float4*>(&sB[buf][wn * 64 + li][(g) * 8 + lh * 4]);                 \
-    B1 = *reinterpret_cast<const float4*>(&sB[buf][wn * 64 + 32 + li][(g) * 8 + lh * 4]);
-#define BIG_MMA8(A, B0, B1)                                                                           \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B0.x, acc0, 0, 0, 0);                            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B1.x, acc1, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B0.y, acc0, 0, 0, 0);                            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B1.y, acc1, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B0.z, acc0, 0, 0, 0);                            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B1.z, acc1, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B0.w, acc0, 0, 0, 0);                            \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B1.w, acc1, 0, 0, 0);
-#define BIG_STEP(buf)                                                                                 \
-    {                                                                                                 \
-        float4 fa0, fb00, fb10, fa1, fb01, fb11;                                                      \
-        BIG_FRAG(buf, 0, fa0, fb00, fb10)                                                             \
-        BIG_FRAG(buf, 1, fa1, fb01, fb11)                                                             \
-        BIG_MMA8(fa0, fb00, fb10)                                                                     \
-        BIG_FRAG(buf, 2, fa0, fb00, fb10)                                                             \
-        BIG_MMA8(fa1, fb01, fb11)                                                                     \
-        BIG_FRAG(buf, 3, fa1, fb01, fb11)                                                             \
-        BIG_MMA8(fa0, fb00, fb10)                                                                     \
-        BIG_MMA8(fa1, fb01, fb11)                                                                     \
-    }
-
-__global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
-    // one array: operand stages during the K loop, the output tile during the epilogue
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BIG_BM + BIG_BN) * BIG_LD];
-    float (*sA)[BIG_BM][BIG_LD] = reinterpret_cast<float (*)[BIG_BM][BIG_LD]>(smem);
-    float (*sB)[BIG_BN][BIG_LD] = reinterpret_cast<float (*)[BIG_BN][BIG_LD]>(smem + 2 * BIG_BM * BIG_LD);
-
-    // Blocks that share X rows (the column tiles of one row tile) are renumbered so that they are
-    // dispatched to the same XCD and meet in its L2 (blocks are dealt round-robin over the 8 XCDs;
-    // a speed choice only).
-    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
-    int lin = blockIdx.y * nbx + blockIdx.x;
-    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
-    const int bx = lin % nbx, by = lin / nbx;
-
-    int pi = L.np - 1;
-    while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
-    const BigProblem& P = L.p[pi];
-    const int n0 = (bx - P.tile_begin) * BIG_BN;
-    const int m0 = by * BIG_BM;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave & 1, wn = wave >> 1;            // wave position in the 2 x 2 grid
-    const int li = lane & 31, lh = lane >> 5;
-    const int K = P.K;
-
-    // global -> register staging: 8 threads cover one 128-byte row segment (32 k)
-    const int srow = tid >> 3, skq = (tid & 7) * 4;
-    const float* xa[2];
-    const float* wb[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
-
-    // two register stages in flight: the loads of K-step s+2 are issued while step s is multiplied, so a
-    // load has two whole steps (~4000 cycles) to arrive even with a single workgroup on the CU
-    const int nk = K / BIG_BK;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 a00, a01, b00, b01, b02, b03;   // stage 0 (even K-steps)
-    float4 a10, a11, b10, b11, b12, b13;   // stage 1 (odd K-steps)
-#define BIG_LOAD(S, ko)                                                     \
-    a##S##0 = *reinterpret_cast<const float4*>(xa[0] + (ko));               \
-    a##S##1 = *reinterpret_cast<const float4*>(xa[1] + (ko));               \
-    b##S##0 = *reinterpret_cast<const float4*>(wb[0] + (ko));               \
-    b##S##1 = *reinterpret_cast<const float4*>(wb[1] + (ko));               \
-    b##S##2 = *reinterpret_cast<const float4*>(wb[2] + (ko));               \
-    b##S##3 = *reinterpret_cast<const float4*>(wb[3] + (ko));
-#define BIG_STORE(S, buf)                                                   \
-    *reinterpret_cast<float4*>(&sA[buf][srow][skq]) = a##S##0;              \
-    *reinterpret_cast<float4*>(&sA[buf][srow + 32][skq]) = a##S##1;         \
-    *reinterpret_cast<float4*>(&sB[buf][srow][skq]) = b##S##0;              \
-    *reinterpret_cast<float4*>(&sB[buf][srow + 32][skq]) = b##S##1;         \
-    *reinterpret_cast<float4*>(&sB[buf][srow + 64][skq]) = b##S##2;         \
-    *reinterpret_cast<float4*>(&sB[buf][srow + 96][skq]) = b##S##3;
-    BIG_LOAD(0, 0)
-    a10 = a11 = b10 = b11 = b12 = b13 = zero4;
-    if (nk > 1) { BIG_LOAD(1, BIG_BK) }
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-    for (int ks = 0; ks < nk; ks += 2) {
-        // even step: stage 0 registers -> LDS buffer 0
-        BIG_STORE(0, 0)
-        __syncthreads();
-        if (ks + 2 < nk) { BIG_LOAD(0, (ks + 2) * BIG_BK) }
-        BIG_STEP(0)
-        if (ks + 1 < nk) {
-            // odd step: stage 1 registers -> LDS buffer 1 (its last readers passed the barrier above)
-            BIG_STORE(1, 1)
-            __syncthreads();
-            if (ks + 3 < nk) { BIG_LOAD(1, (ks + 3) * BIG_BK) }
-            BIG_STEP(1)
-        }
-    }
-#undef BIG_LOAD
-#undef BIG_STORE
-
-    // ---- epilogue.  C layout of 32x32x2: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
-    // The tile goes through LDS so that every thread then owns 4 consecutive columns of a row:
-    // 16-byte table-row reads for the one-hot term and 16-byte coalesced stores.
-    __syncthreads();
-    float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem);   // 64 x 132 words
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = acc0[i];
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
-    }
-    __syncthreads();
-    const int c4 = (tid & 31) * 4;            // 32 threads cover the 128 columns of a row
+// Epilogue shared by the large-row kernels: the 64 x BN output tile lies in LDS (row stride BN + 4 words), every thread
+// owns 4 consecutive columns of a row: + bias, + one-hot table rows (16-byte reads), 16-byte coalesced stores.
+template <int BN>
+__device__ __forceinline__ void big_epilogue(const BigLaunch& L, const BigProblem& P, const float (*sC)[BN + 4], int m0,
+                                             int n0, int tid) {
+    constexpr int TPR = BN / 4;                  // threads per output row
+    const int c4 = (tid % TPR) * 4;
     const int n = n0 + c4;
     if (n >= P.N) return;
     const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
@@ -166,7 +55,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         if (n + 2 < P.N) bias.z = P.bias[n + 2];
         if (n + 3 < P.N) bias.w = P.bias[n + 3];
     }
-    for (int r = tid >> 5; r < BIG_BM; r += 8) {
+    for (int r = tid / TPR; r < BIG_BM; r += 256 / TPR) {
         const int m = m0 + r;
         if (m >= L.M) break;
         float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
@@ -207,152 +96,211 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
     }
 }
 
-// ---- 64 x 64 tiles: the same kernel for launches whose 64 x 128 grid would leave one workgroup per CU --
-// (e.g. 4096 rows x 512 columns = 256 tiles).  Twice the workgroups, two resident per CU, so one
-// workgroup's prologue (first operand fetch) and epilogue overlap the other's K loop.  Waves 2 x 2, one
-// 32 x 32 accumulator each.
-constexpr int BIG_BN64 = 64;
-#define BIG64_FRAG(buf, g, A, B0)                                                                     \
-    A = *reinterpret_cast<const float4*>(&sA[buf][wm * 32 + li][(g) * 8 + lh * 4]);                  \
-    B0 = *reinterpret_cast<const float4*>(&sB[buf][wn * 32 + li][(g) * 8 + lh * 4]);
-#define BIG64_MMA4(A, B0)                                                                             \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, B0.x, acc0, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, B0.y, acc0, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, B0.z, acc0, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, B0.w, acc0, 0, 0, 0);
-#define BIG64_STEP(buf)                                                                               \
-    {                                                                                                 \
-        float4 fa0, fb0, fa1, fb1;                                                                    \
-        BIG64_FRAG(buf, 0, fa0, fb0)                                                                  \
-        BIG64_FRAG(buf, 1, fa1, fb1)                                                                  \
-        BIG64_MMA4(fa0, fb0)                                                                          \
-        BIG64_FRAG(buf, 2, fa0, fb0)                                                                  \
-        BIG64_MMA4(fa1, fb1)                                                                          \
-        BIG64_FRAG(buf, 3, fa1, fb1)                                                                  \
-        BIG64_MMA4(fa0, fb0)                                                                          \
-        BIG64_MMA4(fa1, fb1)                                                                          \
-    }
-
-__global__ __launch_bounds__(256) void k_linear_big64(const BigLaunch L) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BIG_BM + BIG_BN64) * BIG_LD];
+// fp32 form.  NT = 32-column accumulators per wave: 2 -> 64 x 128 tile; 1 -> 64 x 64 tile, for launches whose
+// 128-column grid would leave one workgroup per CU (e.g. 4096 rows x 512 columns = 256 tiles).
+//
+// Schedule of one K-step (32 deep = 4 fragment groups g0..g3 of 8 k, 4 NT MFMAs each) from LDS buffer b, with the
+// next step's operands waiting in registers (loaded two steps ago) and the step after that in flight:
+//
+//     read g2 | MFMA g0 | read g3 | MFMA g1 | registers -> buffer b^1 | MFMA g2 | barrier |
+//     read g0, g1 of buffer b^1 | global loads of step + 3 | MFMA g3
+//
+// so the LDS stores complete under MFMA g2, the barrier finds every wave's LDS traffic finished, and the first
+// fragment reads of the next step and the global-load issue run under MFMA g3: the matrix pipe has work queued across
+// the step boundary.
+//
+// A workgroup walks a sequence of tiles (grid = min(tiles, resident workgroups) when every K is an even number of
+// steps, else one tile each): the K-steps of consecutive tiles form one stream, the loads of "step + 3" past the end
+// of a tile fetch the first steps of the next one, and the finished tile is stored straight from the accumulators
+// (nothing waits for the stores) while the next tile's first fragments are already in registers: no prologue and no
+// drain between tiles.  Past the last tile the loads re-read its last step (no branch in the loop: the load counter
+// the compiler waits on stays exact, only the loads a store needs are waited for).  Problems with a one-hot table
+// take the epilogue through LDS and are launched one tile per workgroup.
+template <int NT>
+__global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
+    constexpr int BN = 64 * NT, NB = 2 * NT;
+    constexpr int STAGE_WORDS = 2 * (BIG_BM + BN) * BIG_LD, TILE_WORDS = BIG_BM * (BN + 4);
+    // one array: operand stages during the K loop, the output tile during the epilogue through LDS
+    __shared__ __attribute__((aligned(16))) float smem[STAGE_WORDS > TILE_WORDS ? STAGE_WORDS : TILE_WORDS];
     float (*sA)[BIG_BM][BIG_LD] = reinterpret_cast<float (*)[BIG_BM][BIG_LD]>(smem);
-    float (*sB)[BIG_BN64][BIG_LD] = reinterpret_cast<float (*)[BIG_BN64][BIG_LD]>(smem + 2 * BIG_BM * BIG_LD);
+    float (*sB)[BN][BIG_LD] = reinterpret_cast<float (*)[BN][BIG_LD]>(smem + 2 * BIG_BM * BIG_LD);
 
-    const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
-    int lin = blockIdx.y * nbx + blockIdx.x;
-    if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
-    const int bx = lin % nbx, by = lin / nbx;
-
-    int pi = L.np - 1;
-    while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
-    const BigProblem& P = L.p[pi];
-    const int n0 = (bx - P.tile_begin) * BIG_BN64;
-    const int m0 = by * BIG_BM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 1, wn = wave >> 1;            // wave position in the 2 x 2 grid
     const int li = lane & 31, lh = lane >> 5;
-    const int K = P.K;
+    const int srow = tid >> 3, skq = (tid & 7) * 4;     // global -> register staging: 8 threads cover one 128-byte row segment
 
-    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    // Tile sequence of this workgroup: tile = tbase + tj, tj += tstride while tj < tlimit.  Workgroups are dealt
+    // round-robin over the 8 XCDs; each XCD gets one contiguous eighth of the tiles (column tiles of a row tile are
+    // consecutive, so they meet in one L2; a speed choice only).
+    const int ntiles = L.ntx * L.nty, G = gridDim.x, w = blockIdx.x;
+    const bool by_xcd = ((ntiles & 7) == 0) && ((G & 7) == 0);
+    const int tbase = by_xcd ? (w & 7) * (ntiles >> 3) : 0;
+    const int tstride = by_xcd ? (G >> 3) : G, tlimit = by_xcd ? (ntiles >> 3) : ntiles;
+    int tj = by_xcd ? (w >> 3) : w;
+    if (tj >= tlimit) return;
+
+    // per-tile state: problem, origin, operand pointers of the thread's staging rows
+    int pi, m0, n0, nk;
     const float* xa[2];
-    const float* wb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
-        wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+    const float* wb[NB];
+    int pin, m0n, n0n, nkn;                               // the same for the next tile of the sequence
+    const float* xan[2];
+    const float* wbn[NB];
+#define BIG_TILE(tile, PI, M0, N0, NK, XA, WB)                                                        \
+    {                                                                                                 \
+        const int bx_ = (tile) % L.ntx, by_ = (tile) / L.ntx;                                         \
+        PI = 0;                                                                                       \
+        _Pragma("unroll") for (int q = 1; q < 4; ++q) PI += (q < L.np && bx_ >= L.p[q].tile_begin) ? 1 : 0;  \
+        const BigProblem& Q = L.p[PI];                                                                \
+        N0 = (bx_ - Q.tile_begin) * BN; M0 = by_ * BIG_BM; NK = Q.K / BIG_BK;                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) XA[i] = Q.X + (int64_t)min(M0 + srow + 32 * i, L.M - 1) * Q.ldx + skq;  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) WB[i] = Q.W + (int64_t)min(N0 + srow + 32 * i, Q.N - 1) * Q.ldw + skq; \
     }
-    const int nk = K / BIG_BK;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 a00, a01, b00, b01;   // stage 0 (even K-steps)
-    float4 a10, a11, b10, b11;   // stage 1 (odd K-steps)
-#define BIG64_LOAD(S, ko)                                                   \
-    a##S##0 = *reinterpret_cast<const float4*>(xa[0] + (ko));               \
-    a##S##1 = *reinterpret_cast<const float4*>(xa[1] + (ko));               \
-    b##S##0 = *reinterpret_cast<const float4*>(wb[0] + (ko));               \
-    b##S##1 = *reinterpret_cast<const float4*>(wb[1] + (ko));
-#define BIG64_STORE(S, buf)                                                 \
-    *reinterpret_cast<float4*>(&sA[buf][srow][skq]) = a##S##0;              \
-    *reinterpret_cast<float4*>(&sA[buf][srow + 32][skq]) = a##S##1;         \
-    *reinterpret_cast<float4*>(&sB[buf][srow][skq]) = b##S##0;              \
-    *reinterpret_cast<float4*>(&sB[buf][srow + 32][skq]) = b##S##1;
-    BIG64_LOAD(0, 0)
-    a10 = a11 = b10 = b11 = zero4;
-    if (nk > 1) { BIG64_LOAD(1, BIG_BK) }
+    BIG_TILE(tbase + tj, pi, m0, n0, nk, xa, wb)
 
-    f32x16 acc0;
+    f32x4 ra0[2], ra1[2], rb0[NB], rb1[NB];            // register stages 0 / 1
+    // operands of K-step `step` of the current tile, or of step - nk of the next tile once step >= nk
+#define BIG_LOAD(S, step)                                                                             \
+    {                                                                                                 \
+        const bool cur_ = (step) < nk;                                                                \
+        const int ko = (cur_ ? (step) : min((step) - nk, nkn - 1)) * BIG_BK;                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra##S[i] = *reinterpret_cast<const f32x4*>((cur_ ? xa[i] : xan[i]) + ko);  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) rb##S[i] = *reinterpret_cast<const f32x4*>((cur_ ? wb[i] : wbn[i]) + ko); \
+    }
+#define BIG_STORE(S, buf)                                                                             \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&sA[buf][srow + 32 * i][skq]) = ra##S[i];  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&sB[buf][srow + 32 * i][skq]) = rb##S[i]; \
+    }
+#define BIG_FRAG(buf, g, F)                                                                           \
+    {                                                                                                 \
+        F##_a = *reinterpret_cast<const f32x4*>(&sA[buf][wm * 32 + li][(g) * 8 + lh * 4]);            \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                \
+            F##_b[j] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * 32 * NT + 32 * j + li][(g) * 8 + lh * 4]); \
+    }
+#define BIG_MMA1(F, c)                                                                                \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(F##_a.c, F##_b[j].c, acc[j], 0, 0, 0);
+#define BIG_MMA(F) BIG_MMA1(F, x) BIG_MMA1(F, y) BIG_MMA1(F, z) BIG_MMA1(F, w)
+#define BIG_FENCE __builtin_amdgcn_sched_barrier(0);   /* the instruction scheduler moves nothing across this point */
+#define BIG_HALF(buf, S, step)                                                                        \
+    {                                                                                                 \
+        BIG_FRAG(buf, 2, fc)                                                                          \
+        BIG_MMA(fa)                                                                                   \
+        BIG_FENCE                                                                                     \
+        BIG_FRAG(buf, 3, fd)                                                                          \
+        BIG_MMA(fb)                                                                                   \
+        BIG_FENCE                                                                                     \
+        BIG_STORE(S, (buf) ^ 1)                                                                       \
+        BIG_FENCE                                                                                     \
+        BIG_MMA(fc)                                                                                   \
+        BIG_FENCE                                                                                     \
+        __syncthreads();                                                                              \
+        BIG_FENCE                                                                                     \
+        BIG_FRAG((buf) ^ 1, 0, fa)                                                                    \
+        BIG_FRAG((buf) ^ 1, 1, fb)                                                                    \
+        BIG_FENCE                                                                                     \
+        BIG_LOAD(S, (step) + 3)                                                                       \
+        BIG_FENCE                                                                                     \
+        BIG_MMA(fd)                                                                                   \
+        BIG_FENCE                                                                                     \
+    }
+
+    f32x16 acc[NT];
+    f32x4 fa_a, fb_a, fc_a, fd_a, fa_b[NT], fb_b[NT], fc_b[NT], fd_b[NT];
+    STAMP_DECL_AT(blockIdx.x < 48)
+    STAMP();
+    // the first tile's prologue (the "next tile" of these loads is never reached: nk >= 1)
+    pin = pi; m0n = m0; n0n = n0; nkn = nk;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc0[i] = 0.f;
+    for (int i = 0; i < 2; ++i) xan[i] = xa[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wbn[i] = wb[i];
+    BIG_LOAD(0, 0)
+    BIG_LOAD(1, 1)
+    BIG_STORE(0, 0)
+    __syncthreads();
+    STAMP();
+    BIG_LOAD(0, 2)
+    BIG_FRAG(0, 0, fa)
+    BIG_FRAG(0, 1, fb)
 
-    for (int ks = 0; ks < nk; ks += 2) {
-        BIG64_STORE(0, 0)
-        __syncthreads();
-        if (ks + 2 < nk) { BIG64_LOAD(0, (ks + 2) * BIG_BK) }
-        BIG64_STEP(0)
-        if (ks + 1 < nk) {
-            BIG64_STORE(1, 1)
-            __syncthreads();
-            if (ks + 3 < nk) { BIG64_LOAD(1, (ks + 3) * BIG_BK) }
-            BIG64_STEP(1)
+    for (;;) {
+        const BigProblem& P = L.p[pi];
+        const bool more = tj + tstride < tlimit;
+        // (no branches in the tile set-up: a branch makes the compiler wait for every load in flight)
+        BIG_TILE(tbase + (more ? tj + tstride : tj), pin, m0n, n0n, nkn, xan, wbn)
+        // bias of the lane's output columns, fetched before the K loop
+        float bias_lane[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            // no branch around the load (a branch here makes the compiler wait for every load in flight)
+            const uintptr_t none = P.bias != nullptr ? (uintptr_t)0 : ~(uintptr_t)0;
+            const float* bp = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(P.bias) | (reinterpret_cast<uintptr_t>(P.W) & none));
+            const float b = bp[min(n0 + wn * 32 * NT + 32 * j + li, P.N - 1)];
+            bias_lane[j] = none ? 0.f : b;
         }
-    }
-#undef BIG64_LOAD
-#undef BIG64_STORE
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-    __syncthreads();
-    float (*sC)[BIG_BN64 + 4] = reinterpret_cast<float (*)[BIG_BN64 + 4]>(smem);   // 64 x 68 words
+        int ks = 0;
+        for (; ks + 1 < nk; ks += 2) {
+            BIG_HALF(0, 1, ks)
+            BIG_HALF(1, 0, ks + 1)
+        }
+        if (ks < nk) BIG_HALF(0, 1, ks)     // odd step count: only ever the last tile of a workgroup (host rule)
+
+        // ---- epilogue.  C layout of 32x32x2: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).
+        STAMP();
+        if (P.tab == nullptr) {
+            // straight from the accumulators: a wave instruction stores two rows x 32 consecutive columns (two whole
+            // 128-byte lines when the output rows are line-aligned)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 + li] = acc0[i];
-    __syncthreads();
-    const int c4 = (tid & 15) * 4;            // 16 threads cover the 64 columns of a row
-    const int n = n0 + c4;
-    if (n >= P.N) return;
-    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.bias) {
-        bias.x = P.bias[n];
-        if (n + 1 < P.N) bias.y = P.bias[n + 1];
-        if (n + 2 < P.N) bias.z = P.bias[n + 2];
-        if (n + 3 < P.N) bias.w = P.bias[n + 3];
-    }
-    for (int r = tid >> 4; r < BIG_BM; r += 16) {
-        const int m = m0 + r;
-        if (m >= L.M) break;
-        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
-        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
-        if (P.tab != nullptr) {
-            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
-            if (vec) {
-                for (int l = 0; l < L.latents; l += 8) {
-                    float4 u[8];
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * 32 * NT + 32 * j + li;
+                if (n < P.N) {
+                    float* out = P.Y + (int64_t)(m0 + wm * 32 + 4 * lh) * P.ldy + n;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int ll = min(l + j, L.latents - 1);
-                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
+                    for (int i = 0; i < 16; ++i) {
+                        const int r = (i & 3) + 8 * (i >> 2);
+                        if (m0 + wm * 32 + 4 * lh + r < L.M) out[(int64_t)r * P.ldy] = acc[j][i] + bias_lane[j];
                     }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
-                }
-            } else {
-                for (int l = 0; l < L.latents; ++l) {
-                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
-                    y.x += tb[0];
-                    if (n + 1 < P.N) y.y += tb[1];
-                    if (n + 2 < P.N) y.z += tb[2];
-                    if (n + 3 < P.N) y.w += tb[3];
                 }
             }
-        }
-        float* out = P.Y + (int64_t)m * P.ldy + n;
-        if (vec) {
-            *reinterpret_cast<float4*>(out) = y;
         } else {
-            out[0] = y.x;
-            if (n + 1 < P.N) out[1] = y.y;
-            if (n + 2 < P.N) out[2] = y.z;
-            if (n + 3 < P.N) out[3] = y.w;
+            // through LDS (16-byte table-row reads and stores); the operand stages are overwritten, so such a tile is
+            // the last of its workgroup
+            __syncthreads();
+            float (*sC)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 * NT + 32 * j + li] = acc[j][i];
+            __syncthreads();
+            big_epilogue<BN>(L, P, sC, m0, n0, tid);
+            break;
         }
+        STAMP();
+        if (!more) break;
+        tj += tstride;
+        pi = pin; m0 = m0n; n0 = n0n; nk = nkn;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xa[i] = xan[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wb[i] = wbn[i];
     }
+    STAMP_FLUSH((unsigned long long)(7000 + NT));
+#undef BIG_TILE
+#undef BIG_LOAD
+#undef BIG_STORE
+#undef BIG_FRAG
+#undef BIG_MMA1
+#undef BIG_MMA
+#undef BIG_HALF
+#undef BIG_FENCE
 }
 
 // ---- bf16 matrix inputs, fp32 accumulation (v_mfma_f32_32x32x16_bf16) ------------------------------
@@ -464,56 +412,7 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
         sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
     }
     __syncthreads();
-    const int c4 = (tid & 31) * 4;
-    const int n = n0 + c4;
-    if (n >= P.N) return;
-    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.bias) {
-        bias.x = P.bias[n];
-        if (n + 1 < P.N) bias.y = P.bias[n + 1];
-        if (n + 2 < P.N) bias.z = P.bias[n + 2];
-        if (n + 3 < P.N) bias.w = P.bias[n + 3];
-    }
-    for (int r = tid >> 5; r < BIG_BM; r += 8) {
-        const int m = m0 + r;
-        if (m >= L.M) break;
-        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
-        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
-        if (P.tab != nullptr) {
-            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
-            if (vec) {
-                for (int l = 0; l < L.latents; l += 8) {
-                    float4 u[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int ll = min(l + j, L.latents - 1);
-                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
-                }
-            } else {
-                for (int l = 0; l < L.latents; ++l) {
-                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
-                    y.x += tb[0];
-                    if (n + 1 < P.N) y.y += tb[1];
-                    if (n + 2 < P.N) y.z += tb[2];
-                    if (n + 3 < P.N) y.w += tb[3];
-                }
-            }
-        }
-        float* out = P.Y + (int64_t)m * P.ldy + n;
-        if (vec) {
-            *reinterpret_cast<float4*>(out) = y;
-        } else {
-            out[0] = y.x;
-            if (n + 1 < P.N) out[1] = y.y;
-            if (n + 2 < P.N) out[2] = y.z;
-            if (n + 3 < P.N) out[3] = y.w;
-        }
-    }
+    big_epilogue<BIG_BN>(L, P, sC, m0, n0, tid);
 }
 
 // ---- fp32 products on the bf16 matrix pipe: exact three-way split -----------------------------------
@@ -684,57 +583,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
         if (NT == 2) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
     }
     __syncthreads();
-    constexpr int TPR = BN / 4;                  // threads per output row
-    const int c4 = (tid % TPR) * 4;
-    const int n = n0 + c4;
-    if (n >= P.N) return;
-    const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.bias) {
-        bias.x = P.bias[n];
-        if (n + 1 < P.N) bias.y = P.bias[n + 1];
-        if (n + 2 < P.N) bias.z = P.bias[n + 2];
-        if (n + 3 < P.N) bias.w = P.bias[n + 3];
-    }
-    for (int r = tid / TPR; r < BIG_BM; r += 256 / TPR) {
-        const int m = m0 + r;
-        if (m >= L.M) break;
-        float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
-        y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
-        if (P.tab != nullptr) {
-            const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
-            if (vec) {
-                for (int l = 0; l < L.latents; l += 8) {
-                    float4 u[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int ll = min(l + j, L.latents - 1);
-                        u[j] = *reinterpret_cast<const float4*>(P.tab + (int64_t)(ll * L.classes + zi[ll]) * P.ldt + n);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (l + j < L.latents) { y.x += u[j].x; y.y += u[j].y; y.z += u[j].z; y.w += u[j].w; }
-                }
-            } else {
-                for (int l = 0; l < L.latents; ++l) {
-                    const float* tb = P.tab + (int64_t)(l * L.classes + zi[l]) * P.ldt + n;
-                    y.x += tb[0];
-                    if (n + 1 < P.N) y.y += tb[1];
-                    if (n + 2 < P.N) y.z += tb[2];
-                    if (n + 3 < P.N) y.w += tb[3];
-                }
-            }
-        }
-        float* out = P.Y + (int64_t)m * P.ldy + n;
-        if (vec) {
-            *reinterpret_cast<float4*>(out) = y;
-        } else {
-            out[0] = y.x;
-            if (n + 1 < P.N) out[1] = y.y;
-            if (n + 2 < P.N) out[2] = y.z;
-            if (n + 3 < P.N) out[3] = y.w;
-        }
-    }
+    big_epilogue<BN>(L, P, sC, m0, n0, tid);
 }
 
 // W (N, K) with row stride ldw -> three bf16 images [3][N][K]: h = bf16(w), m = bf16(w - h), l = bf16(w - h - m)
