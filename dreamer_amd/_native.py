@@ -80,13 +80,13 @@ class drm_observe_io(C.Structure):
                 ("h_out", C.c_void_p), ("zidx_out", C.c_void_p), ("zidx_in_out", C.c_void_p), ("z_out", C.c_void_p),
                 ("post_out", C.c_void_p), ("y_out", C.c_void_p), ("gates_out", C.c_void_p), ("x_out", C.c_void_p),
                 ("h_in_out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("use_graph", C.c_int32)]
+                ("use_graph", C.c_int32), ("precision", C.c_int32)]
 
 
 class drm_observe_bwd_io(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32)] + [(n, C.c_void_p) for n in (
         "c_prev", "y", "wmix", "psoft", "gates", "h_in", "g_h", "g_z", "g_post", "fc_w_hT", "gru_w_ihT", "gru_w_hhT",
-        "lin_zT", "d_gi", "d_gh", "d_x", "d_post", "workspace")] + [("workspace_bytes", C.c_size_t)]
+        "lin_zT", "d_gi", "d_gh", "d_x", "d_post", "workspace")] + [("workspace_bytes", C.c_size_t), ("precision", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/dreamer_amd.h declares

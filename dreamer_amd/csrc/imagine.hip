@@ -644,29 +644,36 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
     }
 }
 
-// Split images of the weight operands of one imagination call (precision 2): made on first use inside the
-// call, found again by (pointer, shape) afterwards.  The area lives in the caller's workspace.
+// bf16 images of the weight operands of one call (precision 2: three planes, the exact split; precision 1: one plane,
+// the rounded weights): made on first use inside the call, found again by (pointer, shape) afterwards.  The area lives
+// in the caller's workspace.
 struct SplitCache {
     uint16_t* base; size_t capacity, used;            // in bf16 elements
+    int planes;
     struct Entry { const float* W; int64_t ldw; int N, K; const uint16_t* planes; } e[64];
     int n;
 };
+static thread_local SplitCache t_split_store{};
 static thread_local SplitCache* t_split = nullptr;
-struct SplitCacheScope {
-    SplitCacheScope(SplitCache* c) { t_split = c; }
-    ~SplitCacheScope() { t_split = nullptr; }
-};
+void big_image_cache_begin(void* base, size_t bytes, int planes) {
+    t_split_store = SplitCache{};
+    t_split_store.base = reinterpret_cast<uint16_t*>(base);
+    t_split_store.capacity = bytes / sizeof(uint16_t);
+    t_split_store.planes = planes;
+    t_split = base != nullptr && bytes > 0 ? &t_split_store : nullptr;
+}
+void big_image_cache_end() { t_split = nullptr; }
 static const uint16_t* split_planes_of(const ProblemSpec& q, hipStream_t stream) {
     SplitCache* c = t_split;
     if (c == nullptr) return nullptr;
     for (int i = 0; i < c->n; ++i)
         if (c->e[i].W == q.W && c->e[i].ldw == q.ldw && c->e[i].N == q.N && c->e[i].K == q.K) return c->e[i].planes;
-    const size_t need = (size_t)3 * q.N * q.K;
-    if (c->n >= 64 || c->used + need > c->capacity) return nullptr;
+    const size_t need = ((size_t)c->planes * q.N * q.K + 7) & ~(size_t)7;      // keeps every image 16-byte aligned
+    if (c->n >= 64 || c->used + need > c->capacity || q.K % 4 != 0) return nullptr;
     uint16_t* planes = c->base + c->used;
     const int64_t total4 = (int64_t)q.N * q.K / 4;
     const int64_t blocks = (total4 + 255) / 256;
-    k_split_planes<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream>>>(q.W, q.ldw, q.N, q.K, planes);
+    k_split_planes<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream>>>(q.W, q.ldw, q.N, q.K, planes, c->planes);
     if (hipGetLastError() != hipSuccess) return nullptr;
     c->e[c->n++] = {q.W, q.ldw, q.N, q.K, planes};
     c->used += need;
@@ -712,13 +719,14 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
         by += 4.0 * (m * k + n * k + n + m * n) + (q.tab ? 4.0 * latents * classes * n + (double)latents * m : 0.0);
     }
     L.np = np; L.M = M; L.zidx = zidx; L.ldz = ldz; L.latents = latents; L.classes = classes;
-    bool presplit = precision == 2;
+    bool presplit = (precision == 2 || precision == 1) && t_split != nullptr && t_split->planes == (precision == 2 ? 3 : 1);
     if (presplit) {   // before the timed scope: the images are made once and serve every later launch of the call
         for (int i = 0; i < np && presplit; ++i) presplit = (L.p[i].Ws = split_planes_of(specs[i], stream)) != nullptr;
     }
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
     const dim3 grid(tiles, (M + BIG_BM - 1) / BIG_BM);
-    if (precision == 1) k_linear_big_bf16<<<grid, dim3(256), 0, stream>>>(L);
+    if (precision == 1 && presplit) k_linear_big_bf16<true><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 1) k_linear_big_bf16<false><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2 && presplit && narrow) k_linear_big_split<true, 1><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2 && presplit) k_linear_big_split<true, 2><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2 && narrow) k_linear_big_split<false, 1><<<grid, dim3(256), 0, stream>>>(L);
@@ -955,12 +963,10 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const bool big = B >= BIG_MIN_ROWS || wide;
     float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
 
-    SplitCache split_cache{};
-    if (prec == 2 && big) {
-        split_cache.base = reinterpret_cast<uint16_t*>(ws + wl.split);
-        split_cache.capacity = wl.split_floats * 2;
-    }
-    SplitCacheScope split_scope(prec == 2 && big ? &split_cache : nullptr);
+    // precision 2: three exact bf16 planes per weight; precision 1: one rounded bf16 image (half the weight bytes per step)
+    struct ImageScope { ~ImageScope() { big_image_cache_end(); } } image_scope;
+    if (prec != 0 && big && std::getenv("DRM_NO_WEIGHT_IMAGES") == nullptr)
+        big_image_cache_begin(ws + wl.split, wl.split_floats * sizeof(float), prec == 2 ? 3 : 1);
 
     const bool few = B <= SKINNY_MAX_ROWS && !wide;
     if (few) {

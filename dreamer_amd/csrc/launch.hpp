@@ -170,6 +170,10 @@ static inline int launch_stbwd(const ProblemSpec& spec, int M, int latents, cons
 // large-row MFMA GEMM (defined next to its kernel in imagine.hip)
 int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                hipStream_t stream, int precision = 0);
+// bf16 images of the weights the large-row launches of the calling thread read, until ..._end(): `base` (16-byte
+// aligned, `bytes` long) receives them on first use; planes = 3 serves precision 2, planes = 1 precision 1
+void big_image_cache_begin(void* base, size_t bytes, int planes);
+void big_image_cache_end();
 
 // ---- few-row path ---------------------------------------------------------------------------------
 // Problems of one launch share their rows and the (RW, CP) shape; LayerNorm is per problem.

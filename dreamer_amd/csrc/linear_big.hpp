@@ -26,7 +26,7 @@ struct BigProblem {
     float* Y; int64_t ldy;
     int N, K;
     int tile_begin;                  // first blockIdx.x (column tile) of this problem
-    const uint16_t* Ws = nullptr;    // split form only: W as three bf16 images [3][N][K] (k_split_planes), or nullptr
+    const uint16_t* Ws = nullptr;    // W as bf16 images [planes][N][K] made by k_split_planes (split form: 3 planes; bf16 form: 1), or nullptr
 };
 
 struct BigLaunch {
@@ -304,15 +304,18 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
 }
 
 // ---- bf16 matrix inputs, fp32 accumulation (v_mfma_f32_32x32x16_bf16) ------------------------------
-// Same tiling and epilogue as k_linear_big.  Operands stay fp32 in memory and are rounded to bf16
-// (round to nearest even) on their way into LDS; a lane's fragment is 8 consecutive k = one 16-byte LDS
-// read, and a K-step of 32 is two MFMAs per 32x32 accumulator instead of sixteen.  LDS image: bf16
-// [row][k], row stride 40 elements (80 bytes): the 16 lanes a ds_read_b128 serves together start 20
-// banks apart and cover all 64 banks once.
+// Same tiling and epilogue as the fp32 form.  The activation operand stays fp32 in memory and is rounded to bf16
+// (round to nearest even) on its way into LDS; the weight operand is either treated the same way (WH = false) or
+// read from a bf16 image [N][K] made once per call by k_split_planes (WH = true: half the weight bytes per step,
+// which is what bounds wide models at few rows).  A lane's fragment is 8 consecutive k = one 16-byte LDS read, and
+// a K-step of 32 is two MFMAs per 32x32 accumulator instead of sixteen.  LDS image: bf16 [row][k], row stride 40
+// elements (80 bytes): the 16 lanes a ds_read_b128 serves together start 20 banks apart and cover all 64 banks once.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BIG_LDH = 40;
 
+template <bool WH>
 __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
     __shared__ __attribute__((aligned(16))) float smem[BIG_BM * (BIG_BN + 4)];   // 64 x 132 floats >= the bf16 stages
     __bf16 (*sA)[BIG_BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BM][BIG_LDH]>(smem);
@@ -336,35 +339,41 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
     const int srow = tid >> 3, skq = (tid & 7) * 4;
     const float* xa[2];
     const float* wb[4];
+    const uint16_t* wh[4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = min(n0 + srow + 32 * i, P.N - 1);
+        wb[i] = P.W + row * P.ldw + skq;
+        wh[i] = WH ? P.Ws + row * K + skq : nullptr;
+    }
 
     const int nk = K / BIG_BK;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 a00, a01, b00, b01, b02, b03;
-    float4 a10, a11, b10, b11, b12, b13;
-#define BIGH_LOAD(S, ko)                                                    \
-    a##S##0 = *reinterpret_cast<const float4*>(xa[0] + (ko));               \
-    a##S##1 = *reinterpret_cast<const float4*>(xa[1] + (ko));               \
-    b##S##0 = *reinterpret_cast<const float4*>(wb[0] + (ko));               \
-    b##S##1 = *reinterpret_cast<const float4*>(wb[1] + (ko));               \
-    b##S##2 = *reinterpret_cast<const float4*>(wb[2] + (ko));               \
-    b##S##3 = *reinterpret_cast<const float4*>(wb[3] + (ko));
+    f32x4 ra0[2], ra1[2], rb0[4], rb1[4];
+    u32x2 rh0[4], rh1[4];
+#define BIGH_LOAD(S, ko)                                                                              \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra##S[i] = *reinterpret_cast<const f32x4*>(xa[i] + (ko));  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            if (WH) rh##S[i] = *reinterpret_cast<const u32x2*>(wh[i] + (ko));                         \
+            else rb##S[i] = *reinterpret_cast<const f32x4*>(wb[i] + (ko));                            \
+        }                                                                                             \
+    }
 #define BIGH_PUT(dst, v)                                                    \
     {                                                                       \
         bf16x4 h;                                                           \
         h[0] = (__bf16)(v).x; h[1] = (__bf16)(v).y; h[2] = (__bf16)(v).z; h[3] = (__bf16)(v).w; \
         *reinterpret_cast<bf16x4*>(dst) = h;                                \
     }
-#define BIGH_STORE(S, buf)                                                  \
-    BIGH_PUT(&sA[buf][srow][skq], a##S##0)                                  \
-    BIGH_PUT(&sA[buf][srow + 32][skq], a##S##1)                             \
-    BIGH_PUT(&sB[buf][srow][skq], b##S##0)                                  \
-    BIGH_PUT(&sB[buf][srow + 32][skq], b##S##1)                             \
-    BIGH_PUT(&sB[buf][srow + 64][skq], b##S##2)                             \
-    BIGH_PUT(&sB[buf][srow + 96][skq], b##S##3)
+#define BIGH_STORE(S, buf)                                                                            \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) BIGH_PUT(&sA[buf][srow + 32 * i][skq], ra##S[i])  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            if (WH) *reinterpret_cast<u32x2*>(&sB[buf][srow + 32 * i][skq]) = rh##S[i];               \
+            else BIGH_PUT(&sB[buf][srow + 32 * i][skq], rb##S[i])                                     \
+        }                                                                                             \
+    }
 #define BIGH_STEP(buf)                                                                                  \
     {                                                                                                   \
         const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(&sA[buf][wm * 32 + li][lh * 8]);            \
@@ -378,9 +387,9 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb01, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb11, acc1, 0, 0, 0);                       \
     }
+    // loads past the last step re-read it (no branch around the loads)
     BIGH_LOAD(0, 0)
-    a10 = a11 = b10 = b11 = b12 = b13 = zero4;
-    if (nk > 1) { BIGH_LOAD(1, BIG_BK) }
+    BIGH_LOAD(1, (nk > 1 ? 1 : 0) * BIG_BK)
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -389,12 +398,12 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
     for (int ks = 0; ks < nk; ks += 2) {
         BIGH_STORE(0, 0)
         __syncthreads();
-        if (ks + 2 < nk) { BIGH_LOAD(0, (ks + 2) * BIG_BK) }
+        BIGH_LOAD(0, min(ks + 2, nk - 1) * BIG_BK)
         BIGH_STEP(0)
         if (ks + 1 < nk) {
             BIGH_STORE(1, 1)
             __syncthreads();
-            if (ks + 3 < nk) { BIGH_LOAD(1, (ks + 3) * BIG_BK) }
+            BIGH_LOAD(1, min(ks + 3, nk - 1) * BIG_BK)
             BIGH_STEP(1)
         }
     }
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
 #undef BIGH_STORE
 #undef BIGH_STEP
 
-    // ---- epilogue (as k_linear_big): tile through LDS, + bias, + one-hot table rows, 16-byte stores
+    // ---- epilogue (as the fp32 form's path through LDS): + bias, + one-hot table rows, 16-byte stores
     __syncthreads();
     float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem);
 #pragma unroll
@@ -586,9 +595,10 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     big_epilogue<BN>(L, P, sC, m0, n0, tid);
 }
 
-// W (N, K) with row stride ldw -> three bf16 images [3][N][K]: h = bf16(w), m = bf16(w - h), l = bf16(w - h - m)
+// W (N, K) with row stride ldw -> bf16 images [planes][N][K]: h = bf16(w) and, with three planes,
+// m = bf16(w - h), l = bf16(w - h - m)
 __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ W, int64_t ldw, int N, int K,
-                                                       uint16_t* __restrict__ planes) {
+                                                       uint16_t* __restrict__ planes, int nplanes) {
     const int64_t total4 = (int64_t)N * K / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t e = i * 4;
@@ -605,8 +615,10 @@ __global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ 
         }
         __bf16* out = reinterpret_cast<__bf16*>(planes);
         *reinterpret_cast<bf16x4*>(out + e) = h;
-        *reinterpret_cast<bf16x4*>(out + (int64_t)N * K + e) = m;
-        *reinterpret_cast<bf16x4*>(out + 2 * (int64_t)N * K + e) = l;
+        if (nplanes == 3) {
+            *reinterpret_cast<bf16x4*>(out + (int64_t)N * K + e) = m;
+            *reinterpret_cast<bf16x4*>(out + 2 * (int64_t)N * K + e) = l;
+        }
     }
 }
 

@@ -33,18 +33,13 @@ struct ResetArgs {
     float* x; int64_t ldxo;
 };
 
-// One workgroup per sequence.  D <= 512: a thread owns at most two columns.
+// One workgroup per sequence; a thread owns columns tid, tid + 256, ...
 template <int LMAX>
 __global__ __launch_bounds__(256) void k_observe_reset_x(const ResetArgs P) {
     __shared__ uint8_t s_z[LMAX];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float c = P.c_prev[(int64_t)b * P.ldc];
     const int a = (int)P.a_prev[(int64_t)b * P.lda];
-    const int i0 = tid, i1 = tid + 256;
-    const bool jn0 = i0 < P.D, jn1 = i1 < P.D;
-    const float hp0 = jn0 ? P.h_prev[(int64_t)b * P.ldh + i0] : 0.f, hp1 = jn1 ? P.h_prev[(int64_t)b * P.ldh + i1] : 0.f;
-    const float at0 = jn0 ? P.a_tab[(int64_t)a * P.D + i0] : 0.f, at1 = jn1 ? P.a_tab[(int64_t)a * P.D + i1] : 0.f;
-    float xz0 = jn0 ? P.lin_b[i0] : 0.f, xz1 = jn1 ? P.lin_b[i1] : 0.f;
     if (c != 0.f) {
         if (tid < P.L) s_z[tid] = P.z_prev[(int64_t)b * P.ldz + tid];
     } else {
@@ -74,18 +69,135 @@ __global__ __launch_bounds__(256) void k_observe_reset_x(const ResetArgs P) {
     }
     __syncthreads();
     if (tid < P.L) P.z_in[(int64_t)b * P.ldzi + tid] = s_z[tid];
-    float u0[LMAX], u1[LMAX];
+    for (int i0 = 0; i0 < P.D; i0 += 512) {
+        const int c0 = i0 + tid, c1 = i0 + tid + 256;
+        const bool jn0 = c0 < P.D, jn1 = c1 < P.D;
+        const float hp0 = jn0 ? P.h_prev[(int64_t)b * P.ldh + c0] : 0.f, hp1 = jn1 ? P.h_prev[(int64_t)b * P.ldh + c1] : 0.f;
+        const float at0 = jn0 ? P.a_tab[(int64_t)a * P.D + c0] : 0.f, at1 = jn1 ? P.a_tab[(int64_t)a * P.D + c1] : 0.f;
+        float xz0 = jn0 ? P.lin_b[c0] : 0.f, xz1 = jn1 ? P.lin_b[c1] : 0.f;
+        float u0[LMAX], u1[LMAX];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-        const bool ok = l < P.L;
-        const int64_t rowoff = ok ? (int64_t)(l * P.classes + s_z[l]) * P.D : 0;
-        u0[l] = (ok && jn0) ? P.lin_zT[rowoff + i0] : 0.f;
-        u1[l] = (ok && jn1) ? P.lin_zT[rowoff + i1] : 0.f;
+        for (int l = 0; l < LMAX; ++l) {
+            const bool ok = l < P.L;
+            const int64_t rowoff = ok ? (int64_t)(l * P.classes + s_z[l]) * P.D : 0;
+            u0[l] = (ok && jn0) ? P.lin_zT[rowoff + c0] : 0.f;
+            u1[l] = (ok && jn1) ? P.lin_zT[rowoff + c1] : 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { xz0 += u0[l]; xz1 += u1[l]; }
+        if (jn0) { P.x[(int64_t)b * P.ldxo + c0] = xz0 + c * at0; P.h_in[(int64_t)b * P.ldhi + c0] = c * hp0; }
+        if (jn1) { P.x[(int64_t)b * P.ldxo + c1] = xz1 + c * at1; P.h_in[(int64_t)b * P.ldhi + c1] = c * hp1; }
     }
+}
+
+// ---- wide path (recurrent width > 512, any number of sequences) ------------------------------------
+// The matrix products run on the large-row kernel (launch_big); what surrounds them is elementwise.
+// GRU cell of one step over (B, D): gi = W_ih x (no bias), gh_raw = W_hh h_{t-1} (no bias, not yet scaled by the
+// continue flag: W_hh (c h) = c W_hh h); writes h_t and the saved gate values r, u, n, gh_n.
+struct WideGatesArgs {
+    const float* gi; const float* gh_raw;      // (B, 3D) contiguous
+    const float* b_ih; const float* b_hh;      // (3D)
+    const float* c_prev; int64_t ldc;          // (B)
+    const float* h_prev; int64_t ldh;
+    float* h_out; int64_t ldho;
+    float* gates_out; int64_t ldgo;            // (B, 4D)
+    int B, D;
+};
+__global__ __launch_bounds__(256) void k_observe_gates_wide(const WideGatesArgs P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)P.B * P.D) return;
+    const int D = P.D, b = (int)(idx / D), j = (int)(idx - (int64_t)b * D);
+    const float c = P.c_prev[(int64_t)b * P.ldc];
+    const float* gi = P.gi + (int64_t)b * 3 * D;
+    const float* gh = P.gh_raw + (int64_t)b * 3 * D;
+    const float ghr = gh[j] * c + P.b_hh[j], ghu = gh[D + j] * c + P.b_hh[D + j], ghn = gh[2 * D + j] * c + P.b_hh[2 * D + j];
+    const float hp = P.h_prev[(int64_t)b * P.ldh + j] * c;
+    const float rr = sigmoid_f((gi[j] + P.b_ih[j]) + ghr);
+    const float uu = sigmoid_f((gi[D + j] + P.b_ih[D + j]) + ghu);
+    const float nn = tanhf((gi[2 * D + j] + P.b_ih[2 * D + j]) + rr * ghn);
+    P.h_out[(int64_t)b * P.ldho + j] = (1.0f - uu) * nn + uu * hp;
+    float* go = P.gates_out + (int64_t)b * P.ldgo;
+    go[j] = rr; go[D + j] = uu; go[2 * D + j] = nn; go[3 * D + j] = ghn;
+}
+
+// Posterior logits = raw (W_fc_h h_t) + e_part, then the draw of z_t (eight lanes per latent): writes the logits, the
+// soft sample probabilities y = q / sum q with q_k = ((1 - eps) softmax_k + eps / K) / E_k, the index and the one-hot.
+struct WideSampleArgs {
+    const float* raw; int64_t ldraw;           // (B, L*32)
+    const float* e_part; int64_t ldep;
+    const float* expo; int64_t lde;
+    float* post_out; int64_t ldpo;
+    float* y_out; int64_t ldy;
+    uint8_t* zidx_out; int64_t ldzo;
+    float* z_dense; int64_t ldzd;              // or nullptr
+    int B, L;
+    float one_m_eps, eps_over_k;
+};
+__global__ __launch_bounds__(256) void k_observe_sample_wide(const WideSampleArgs P) {
+    const int sub = threadIdx.x & 7, k0 = sub * 4;
+    const int64_t total = (int64_t)P.B * P.L;
+    for (int64_t it = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); it < total; it += (int64_t)gridDim.x * 32) {
+        const int b = (int)(it / P.L), l = (int)(it - (int64_t)b * P.L);
+        const float4 rw = *reinterpret_cast<const float4*>(P.raw + (int64_t)b * P.ldraw + l * 32 + k0);
+        const float4 ep = *reinterpret_cast<const float4*>(P.e_part + (int64_t)b * P.ldep + l * 32 + k0);
+        const float4 ex = *reinterpret_cast<const float4*>(P.expo + (int64_t)b * P.lde + l * 32 + k0);
+        const float v[4] = {rw.x + ep.x, rw.y + ep.y, rw.z + ep.z, rw.w + ep.w};
+        const float e[4] = {ex.x, ex.y, ex.z, ex.w};
+        const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float pj[4], s = 0.f;
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) { xz0 += u0[l]; xz1 += u1[l]; }
-    if (jn0) { P.x[(int64_t)b * P.ldxo + i0] = xz0 + c * at0; P.h_in[(int64_t)b * P.ldhi + i0] = c * hp0; }
-    if (jn1) { P.x[(int64_t)b * P.ldxo + i1] = xz1 + c * at1; P.h_in[(int64_t)b * P.ldhi + i1] = c * hp1; }
+        for (int i = 0; i < 4; ++i) { pj[i] = expf(v[i] - mx); s += pj[i]; }
+        const float scale = P.one_m_eps / group_sum<8>(s);
+        float q[4], qs = 0.f, best = -1.f;
+        int bi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[i] = fmaf(pj[i], scale, P.eps_over_k) / e[i];
+            qs += q[i];
+            if (q[i] > best) { best = q[i]; bi = k0 + i; }
+        }
+        qs = group_sum<8>(qs);
+        group_argmax<8>(best, bi);
+        *reinterpret_cast<float4*>(P.post_out + (int64_t)b * P.ldpo + l * 32 + k0) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(P.y_out + (int64_t)b * P.ldy + l * 32 + k0) = make_float4(q[0] / qs, q[1] / qs, q[2] / qs, q[3] / qs);
+        if (sub == 0) P.zidx_out[(int64_t)b * P.ldzo + l] = (uint8_t)bi;
+        if (P.z_dense)
+            *reinterpret_cast<float4*>(P.z_dense + (int64_t)b * P.ldzd + l * 32 + k0) =
+                make_float4(bi == k0 ? 1.f : 0.f, bi == k0 + 1 ? 1.f : 0.f, bi == k0 + 2 ? 1.f : 0.f, bi == k0 + 3 ? 1.f : 0.f);
+    }
+}
+
+// GRU cell backward of one step over (B, D):
+//     dh = dh_fc + g_h + c_{t+1} (dhu_next + dhw_next)      (dh_fc = d(post)_t W_fc_h, dhw = d(gh)_{t+1} W_hh)
+// then d(gi), d(gh) from the saved gates, and dhu = dh * u for the step before.
+struct WideGruBwdArgs {
+    const float* dh_fc;                        // (B, D) contiguous
+    const float* g_h; int64_t ldgh;
+    const float* dhu_next; const float* dhw_next;   // (B, D) contiguous; dhu_next == nullptr at the last step
+    const float* next_scale; int64_t ldns;
+    const float* gates; int64_t ldg;           // (B, 4D)
+    const float* h_in; int64_t ldhi;
+    float* dgi; float* dgh; int64_t lddg;      // (B, 3D)
+    float* dhu;                                // (B, D) contiguous (may alias dhu_next)
+    int B, D;
+};
+__global__ __launch_bounds__(256) void k_observe_gru_bwd_wide(const WideGruBwdArgs P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)P.B * P.D) return;
+    const int D = P.D, m = (int)(idx / D), n = (int)(idx - (int64_t)m * D);
+    float dh = P.dh_fc[idx] + P.g_h[(int64_t)m * P.ldgh + n];
+    if (P.dhu_next != nullptr) dh += P.next_scale[(int64_t)m * P.ldns] * (P.dhu_next[idx] + P.dhw_next[idx]);
+    const float* gt = P.gates + (int64_t)m * P.ldg;
+    const float rr = gt[n], uu = gt[D + n], nn = gt[2 * D + n], ghn = gt[3 * D + n];
+    const float hin = P.h_in[(int64_t)m * P.ldhi + n];
+    const float dn_pre = dh * (1.0f - uu) * (1.0f - nn * nn);
+    const float du_pre = dh * (hin - nn) * uu * (1.0f - uu);
+    const float dr_pre = dn_pre * ghn * rr * (1.0f - rr);
+    float* gi = P.dgi + (int64_t)m * P.lddg;
+    float* gh = P.dgh + (int64_t)m * P.lddg;
+    gi[n] = dr_pre; gi[D + n] = du_pre; gi[2 * D + n] = dn_pre;
+    gh[n] = dr_pre; gh[D + n] = du_pre; gh[2 * D + n] = dn_pre * rr;
+    P.dhu[idx] = dh * uu;
 }
 
 // ---- few-sequence path ---------------------------------------------------------------------------
@@ -331,7 +443,7 @@ __global__ __launch_bounds__(256) void k_action_table_o(const float* __restrict_
 
 static int check_observe_dims(const drm_dims& d) {
     DRM_REQUIRE(d.K == 32, DRM_ENOTSUP, "classes per latent must be 32 (got %d)", d.K);
-    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.D <= 512, DRM_ENOTSUP, "D=%d must be a multiple of 32, at most 512", d.D);
+    DRM_REQUIRE(d.D >= 32 && d.D % 32 == 0 && d.D <= 4096, DRM_ENOTSUP, "D=%d must be a multiple of 32, at most 4096", d.D);
     DRM_REQUIRE(d.L >= 1 && d.L <= MAX_LATENTS, DRM_ENOTSUP, "latents=%d (max %d)", d.L, MAX_LATENTS);
     DRM_REQUIRE(d.A >= 1 && d.E >= 1, DRM_EINVAL, "A=%d E=%d", d.A, d.E);
     return DRM_OK;
@@ -370,6 +482,72 @@ static int observe_enqueue(const drm_observe_weights* w, const drm_observe_io* i
     const float lek = (float)(log((double)d.unimix_eps) - log((double)d.K));
     const int64_t TD = (int64_t)T * D, TL = (int64_t)T * L, TLK = (int64_t)T * LK;
 
+    if (D > 512) {
+        // ---- wide recurrent state: per step reset + x gather, gi = W_ih x, gates, (W_fc_h h || W_hh h), draw
+        DRM_REQUIRE(io->precision == 0 || io->precision == 1, DRM_EINVAL, "precision=%d", io->precision);
+        const size_t act_floats = ((size_t)B * (6 * (size_t)D + LK) + 3) & ~(size_t)3;
+        DRM_REQUIRE(io->workspace_bytes >= act_floats * sizeof(float), DRM_EINVAL, "workspace too small");
+        const int prec = io->precision;
+        float* gi = ghraw + (size_t)B * 3 * D;
+        float* praw = gi + (size_t)B * 3 * D;
+        // bf16 products: the three weight matrices are rounded once per call into the rest of the workspace (when it
+        // was sized by drm_observe_workspace_bytes) and every step reads those images, half the bytes
+        struct ImageScope { ~ImageScope() { big_image_cache_end(); } } image_scope;
+        if (prec == 1 && std::getenv("DRM_NO_WEIGHT_IMAGES") == nullptr)
+            big_image_cache_begin(ghraw + act_floats, io->workspace_bytes - act_floats * sizeof(float), 1);
+        {
+            ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D};
+            if (int rc = launch_big(&p, 1, B, nullptr, 0, 0, 0, s, prec)) return rc;
+        }
+        for (int t = 0; t < T; ++t) {
+            const float* h_prev = t == 0 ? io->h0 : io->h_out + (size_t)(t - 1) * D;
+            const int64_t ldh = t == 0 ? D : TD;
+            float* h_t = io->h_out + (size_t)t * D;
+            {
+                ResetArgs a{};
+                a.h_prev = h_prev; a.ldh = ldh;
+                a.z_prev = t == 0 ? io->zidx0 : io->zidx_out + (size_t)(t - 1) * L; a.ldz = t == 0 ? L : TL;
+                a.a_prev = io->a_prev + t; a.lda = T; a.c_prev = io->c_prev + t; a.ldc = T;
+                a.expo = io->expo_reset + (size_t)t * B * LK;
+                a.lin_zT = w->pack + pl.lin_zT; a.lin_b = w->lin_b; a.a_tab = w->pack + pl.a_tab;
+                a.D = D; a.L = L; a.classes = d.K;
+                a.z_in = io->zidx_in_out + (size_t)t * L; a.ldzi = TL;
+                a.h_in = io->h_in_out + (size_t)t * D; a.ldhi = TD; a.x = io->x_out + (size_t)t * D; a.ldxo = TD;
+                ProfScope prof(PC_ACTOR_HEAD, s, (double)B * D * (L + 2), 4.0 * (double)B * D * (L + 4));
+                if (L <= 32) k_observe_reset_x<32><<<dim3(B), dim3(256), 0, s>>>(a);
+                else k_observe_reset_x<64><<<dim3(B), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+            {
+                ProblemSpec p{io->x_out + (size_t)t * D, TD, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, gi, 3 * D, 3 * D, D};
+                if (int rc = launch_big(&p, 1, B, nullptr, 0, 0, 0, s, prec)) return rc;
+            }
+            {
+                WideGatesArgs a{gi, ghraw, w->gru_b_ih, w->gru_b_hh, io->c_prev + t, T, h_prev, ldh, h_t, TD,
+                                io->gates_out + (size_t)t * 4 * D, (int64_t)T * 4 * D, B, D};
+                ProfScope prof(PC_ELEMENTWISE, s, 20.0 * B * D, 4.0 * 12.0 * B * D);
+                k_observe_gates_wide<<<dim3((unsigned)(((int64_t)B * D + 255) / 256)), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+            {
+                ProblemSpec p[2] = {
+                    {h_t, TD, nullptr, nullptr, w->fc_w_h, w->ld_fc, nullptr, nullptr, 0, praw, LK, LK, D},
+                    {h_t, TD, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D}};
+                if (int rc = launch_big(p, t + 1 < T ? 2 : 1, B, nullptr, 0, 0, 0, s, prec)) return rc;
+            }
+            {
+                WideSampleArgs a{praw, LK, io->e_part + (size_t)t * LK, TLK, io->expo_z + (size_t)t * B * LK, LK,
+                                 io->post_out + (size_t)t * LK, TLK, io->y_out + (size_t)t * LK, TLK,
+                                 io->zidx_out + (size_t)t * L, TL, io->z_out ? io->z_out + (size_t)t * LK : nullptr, TLK, B, L,
+                                 1.0f - d.unimix_eps, d.unimix_eps / (float)d.K};
+                const int64_t blocks = ((int64_t)B * L + 31) / 32;
+                ProfScope prof(PC_SAMPLE, s, 12.0 * B * LK, (double)B * L * (4.0 * 128.0 + 128.0 + 1.0));
+                k_observe_sample_wide<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+        }
+        return DRM_OK;
+    }
     if (B <= SKINNY_MAX_ROWS) {
         {   // gh_raw for step 0 from h0
             ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, nullptr, nullptr, 0, ghraw, 3 * D, 3 * D, D};
@@ -505,6 +683,7 @@ extern "C" int drm_pack_observe(const drm_observe_weights* w, float* pack_out, s
     ProblemSpec gz{pack_out + pl.lin_zT, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
                    pack_out + pl.gz, 3 * d.D, 3 * d.D, d.D};
     if (int rc = launch_big(&gz, 1, LK, nullptr, 0, 0, 0, s)) return rc;
+    if (d.D > 512) return DRM_OK;      // the wide path forms gi = W_ih x per step; it reads gz only (backward pass)
     ProblemSpec ga{pack_out + pl.a_tab, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
                    pack_out + pl.ga, 3 * d.D, 3 * d.D, d.D};
     if (d.A <= SKINNY_MAX_ROWS) { if (int rc = launch_skinny(&ga, 1, d.A, s)) return rc; }
@@ -517,6 +696,12 @@ extern "C" int drm_pack_observe(const drm_observe_weights* w, float* pack_out, s
 
 extern "C" size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, int32_t T) {
     if (!dims || check_observe_dims(*dims) != DRM_OK || B < 1 || T < 1) return 0;
+    if (dims->D > 512) {
+        // activations of one step + room for bf16 images of W_ih, W_hh, W_fc_h (precision 1)
+        const size_t D = dims->D, LK = (size_t)dims->L * dims->K;
+        const size_t act = ((size_t)B * (6 * D + LK) + 3) & ~(size_t)3;
+        return act * sizeof(float) + (6 * D * D + LK * D + 64) * sizeof(uint16_t);
+    }
     return (size_t)B * 3 * dims->D * sizeof(float);
 }
 
@@ -559,6 +744,12 @@ extern "C" size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t 
     if (!dims || check_observe_dims(*dims) != DRM_OK || B < 1) return 0;
     // many sequences: dh*u and two alternating dh_next buffers; few: dh*u, d(gh) W_hh, and dz_raw
     const size_t a = (size_t)B * 3 * dims->D, b = (size_t)B * (2 * (size_t)dims->D + (size_t)dims->L * dims->K);
+    if (dims->D > 512) {
+        // activations of one step + room for bf16 images of gz, W_hh^T, W_fc_h^T, W_ih^T (precision 1)
+        const size_t D = dims->D, LK = (size_t)dims->L * dims->K;
+        const size_t act = ((size_t)B * (3 * D + LK) + 3) & ~(size_t)3;
+        return act * sizeof(float) + (6 * D * D + 4 * LK * D + 64) * sizeof(uint16_t);
+    }
     return (a > b ? a : b) * sizeof(float);
 }
 
@@ -575,6 +766,56 @@ extern "C" int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_
                 DRM_EINVAL, "workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
     float* dhu = (float*)io->workspace;
+    if (D > 512) {
+        // ---- wide recurrent state: the few-sequence decomposition below with the products on the large-row kernel
+        DRM_REQUIRE(io->precision == 0 || io->precision == 1, DRM_EINVAL, "precision=%d", io->precision);
+        const size_t act_floats = ((size_t)B * (3 * (size_t)D + LK) + 3) & ~(size_t)3;
+        DRM_REQUIRE(io->workspace_bytes >= act_floats * sizeof(float), DRM_EINVAL, "workspace too small");
+        const int prec = io->precision;
+        struct ImageScope { ~ImageScope() { big_image_cache_end(); } } image_scope;
+        if (prec == 1 && std::getenv("DRM_NO_WEIGHT_IMAGES") == nullptr)
+            big_image_cache_begin(dhu + act_floats, io->workspace_bytes - act_floats * sizeof(float), 1);
+        const ObsPack pl = obs_pack_layout(d);
+        const float* gz = io->lin_zT + pl.gz;
+        float* dhw = dhu + (size_t)B * D;
+        float* dhfc = dhw + (size_t)B * D;
+        float* dzraw = dhfc + (size_t)B * D;
+        const int64_t TD_ = (int64_t)T * D, T3D_ = (int64_t)T * 3 * D, TLK_ = (int64_t)T * LK;
+        for (int t = T - 1; t >= 0; --t) {
+            const bool last = t == T - 1;
+            if (!last) {
+                ProblemSpec p[2] = {
+                    {io->d_gi + (size_t)(t + 1) * 3 * D, T3D_, nullptr, nullptr, gz, 3 * D, nullptr, nullptr, 0, dzraw, LK, LK, 3 * D},
+                    {io->d_gh + (size_t)(t + 1) * 3 * D, T3D_, nullptr, nullptr, io->gru_w_hhT, 3 * D, nullptr, nullptr, 0, dhw, D, D,
+                     3 * D}};
+                if (int rc = launch_big(p, 2, B, nullptr, 0, 0, 0, s, prec)) return rc;
+            }
+            {
+                StBwdArgs a{};
+                a.dz_raw = last ? nullptr : dzraw; a.lddz = LK; a.scale = last ? nullptr : io->c_prev + (t + 1); a.lds = T;
+                a.g_z = io->g_z + (size_t)t * LK; a.y = io->y + (size_t)t * LK; a.wmix = io->wmix + (size_t)t * LK;
+                a.psoft = io->psoft + (size_t)t * LK; a.g_post = io->g_post + (size_t)t * LK; a.ldl = TLK_;
+                a.dpost = io->d_post + (size_t)t * LK; a.lddp = TLK_; a.L = L;
+                ProfScope prof(PC_SAMPLE, s, 12.0 * B * LK, 28.0 * B * LK);
+                k_observe_st_bwd<<<dim3(B), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+            {
+                ProblemSpec p{io->d_post + (size_t)t * LK, TLK_, nullptr, nullptr, io->fc_w_hT, LK, nullptr, nullptr, 0, dhfc, D, D, LK};
+                if (int rc = launch_big(&p, 1, B, nullptr, 0, 0, 0, s, prec)) return rc;
+            }
+            {
+                WideGruBwdArgs a{dhfc, io->g_h + (size_t)t * D, TD_, last ? nullptr : dhu, dhw, last ? nullptr : io->c_prev + (t + 1), T,
+                                 io->gates + (size_t)t * 4 * D, (int64_t)T * 4 * D, io->h_in + (size_t)t * D, TD_,
+                                 io->d_gi + (size_t)t * 3 * D, io->d_gh + (size_t)t * 3 * D, T3D_, dhu, B, D};
+                ProfScope prof(PC_ELEMENTWISE, s, 24.0 * B * D, 4.0 * 16.0 * B * D);
+                k_observe_gru_bwd_wide<<<dim3((unsigned)(((int64_t)B * D + 255) / 256)), dim3(256), 0, s>>>(a);
+                DRM_LAUNCH_CHECK();
+            }
+        }
+        ProblemSpec px{io->d_gi, 3 * D, nullptr, nullptr, io->gru_w_ihT, 3 * D, nullptr, nullptr, 0, io->d_x, D, D, 3 * D};
+        return launch_big(&px, 1, B * T, nullptr, 0, 0, 0, s, prec);
+    }
     if (B <= SKINNY_MAX_ROWS && 3 * D <= 1536 && LK <= 1536) {
         // ---- few sequences: three launches per step on ~256 workgroups each.  z enters the GRU only
         // through gi = W_ih x and x is linear in the one-hot z, so d(z_t) = d(gi_{t+1}) gz^T with the

@@ -11,6 +11,11 @@ Only this part of ``WorldModel.loss`` is sequential in time (lib/world_model.py:
 ``observe_scan`` dispatches on the device of its inputs: HIP tensors go to the fused kernels
 (``ObserveScanFn``, a torch.autograd.Function: native forward over all T steps, explicit reverse-time
 backward), host tensors to the eager loop (the reference supports ``device="cpu"`` as well).
+
+Recurrent widths up to 512 run on the register-resident few-row / small-tile kernels; wider states (up to
+4096) take the same decomposition with every matrix product on the large-row MFMA kernel.  For those,
+``wm.observe_precision = "bf16"`` rounds the operands of the products to bf16 on their way into the matrix
+cores (fp32 accumulation; gates, draws and resets stay fp32): results within 1e-2 of the fp32 path.
 """
 from __future__ import annotations
 
@@ -53,6 +58,7 @@ class _ObserveEngine:
             raise N.NativeError(f"unsupported dimensions: {N.lib().drm_last_error().decode()}")
         self.pack = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
         self.ws = None
+        self.precision = 0
 
     def weights(self, a_emb, lin_w, lin_b, w_ih, w_hh, b_ih, b_hh, fc_w_h):
         N = self.N
@@ -99,6 +105,7 @@ class ObserveScanFn(torch.autograd.Function):
         io.x_out, io.h_in_out = x.data_ptr(), h_in.data_ptr()
         io.workspace, io.workspace_bytes = eng.ws.data_ptr(), eng.ws.numel() * 4
         io.use_graph = 0
+        io.precision = eng.precision
         N.check(N.lib().drm_observe_forward_f32(C.byref(w), C.byref(io), N.stream_ptr(dev)), "drm_observe_forward_f32")
         ctx.save_for_backward(a_emb, lin_w, w_ih, w_hh, fc_w_h, a_prev, c_prev, h, zidx_in, post, y, gates, x, h_in)
         ctx.eps = float(d.unimix_eps)
@@ -139,6 +146,7 @@ class ObserveScanFn(torch.autograd.Function):
         io.fc_w_hT, io.gru_w_ihT, io.gru_w_hhT, io.lin_zT = fcT.data_ptr(), ihT.data_ptr(), hhT.data_ptr(), eng.pack.data_ptr()
         io.d_gi, io.d_gh, io.d_x, io.d_post = d_gi.data_ptr(), d_gh.data_ptr(), d_x.data_ptr(), d_post.data_ptr()
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        io.precision = eng.precision
         N.check(N.lib().drm_observe_backward_f32(C.byref(eng.dims), C.byref(io), N.stream_ptr(dev)), "drm_observe_backward_f32")
         # weight gradients: one batched product each over all B*T rows
         gi2, gh2, dx2 = d_gi.reshape(B * T, -1), d_gh.reshape(B * T, -1), d_x.reshape(B * T, D)
@@ -162,8 +170,7 @@ def observe_scan(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state, engine_a
     ``engine_attr`` names the attribute of ``wm`` that holds the packed tables and workspace; a caller
     whose launches are recorded into a graph uses one of its own, so that no other caller ever
     reallocates the buffers the recording points to."""
-    if not e_part.is_cuda or state.h.size(-1) > 512:
-        # host tensors, or a recurrent width beyond what the scan kernels are built for (D <= 512)
+    if not e_part.is_cuda:
         return _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state)
     from . import _native as N
     from .world_model import WorldModelState
@@ -171,6 +178,10 @@ def observe_scan(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state, engine_a
     if eng is None:
         eng = _ObserveEngine(wm)
         object.__setattr__(wm, engine_attr, eng)
+    prec = getattr(wm, "observe_precision", "f32")
+    if prec not in ("f32", "bf16"):
+        raise ValueError(f"observe_precision must be 'f32' or 'bf16' (got {prec!r})")
+    eng.precision = 1 if (prec == "bf16" and wm.hidden_size > 512) else 0
     B, T = a_prev.shape
     L, K = wm.num_latents, wm.classes_per_latent
     g = wm.seq.gru

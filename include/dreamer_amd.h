@@ -371,6 +371,8 @@ typedef struct drm_observe_io {
     float* h_in_out;          /* (B,T,D) c * h_{t-1} */
     void* workspace; size_t workspace_bytes;
     int32_t use_graph;
+    int32_t precision;        /* recurrent widths > 512 only: 0 = fp32 products, 1 = operands rounded to bf16 on their way
+                                 into the matrix cores (fp32 accumulation; gates, draw and reset stay fp32) */
 } drm_observe_io;
 
 size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, int32_t T);
@@ -404,6 +406,7 @@ typedef struct drm_observe_bwd_io {
     float* d_x;               /* (B,T,D) */
     float* d_post;            /* (B,T,L*K) */
     void* workspace; size_t workspace_bytes;   /* >= drm_observe_bwd_workspace_bytes */
+    int32_t precision;        /* as in drm_observe_io (recurrent widths > 512 only) */
 } drm_observe_bwd_io;
 
 size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t B);

@@ -126,3 +126,65 @@ def test_act_step_runs_the_scan_kernels_and_matches_step(B):
         assert torch.equal(got.z, (ref.z > 0.5).float())
         assert torch.equal(after_ref, after_got)
         state, c = got, torch.ones(B, 1, device=DEV)
+
+
+@pytest.mark.parametrize("D,B,T", [(1024, 5, 4), (640, 70, 3), (4096, 2, 3)])
+def test_wide_recurrent_state_matches_oracle_and_host_path(D, B, T):
+    """Recurrent widths beyond 512 (up to the scaled model's 4096) run the scan with every product on the large-row
+    kernel: forward values against the oracle's step-by-step loss, every gradient against the host eager path."""
+    import oracle.dreamer_oracle as O
+    from helpers import weights_of
+    d = dict(DIMS["small"], D=D, M=64, L=8, A=5, T=T)
+    salt = 900 + B
+    wm_gpu, _, _ = build_models(d, salt)
+    wm_cpu, _, _ = build_models(d, salt)
+    ww = weights_of(wm_cpu)
+    wm_gpu = wm_gpu.to(DEV)
+    obs, actions, rewards, continues, noise = observe_inputs(d, salt, B)
+    continues[:, 1] = False   # a reset in every sequence
+    with torch.no_grad():
+        ref_total, ref = O.wm_loss(ww, obs.float() / 255.0, actions, rewards, continues, noise["init"], noise["reset"], noise["z"])
+    lg, ig = wm_gpu.loss(obs.to(DEV).float() / 255.0, actions.to(DEV), rewards.to(DEV), continues.to(DEV),
+                         noise={k: v.to(DEV) for k, v in noise.items()})
+    assert torch.equal(ig["z"].detach().argmax(-1).cpu(), ref["idx"])
+    assert rel_err(ig["h"].detach().cpu(), ref["h"]) < TOL
+    assert rel_err(ig["post_logits"].detach().cpu(), ref["post_logits"]) < TOL
+    assert rel_err(ig["prior_logits"].detach().cpu(), ref["prior_logits"]) < TOL
+    assert rel_err(lg.detach().cpu(), ref_total) < TOL
+    for key in ("pred", "dyn", "rep"):
+        assert rel_err(ig[key + "_loss"].detach().cpu(), ref[key + "_loss"]) < TOL, key
+    lc, _ = wm_cpu.loss(obs.float() / 255.0, actions, rewards, continues, noise=noise)
+    lc.backward(); lg.backward()
+    pc, pg = dict(wm_cpu.named_parameters()), dict(wm_gpu.named_parameters())
+    for name, p in pc.items():
+        if p.grad is None:
+            assert pg[name].grad is None, name
+        else:
+            assert rel_err(pg[name].grad.cpu(), p.grad) < 2e-4, name
+
+
+def test_wide_recurrent_state_with_bf16_matrix_inputs():
+    """The scaled model's width (4096) with the operands of the scan's products rounded to bf16 (fp32 accumulation):
+    same draws, states, logits, loss and gradients within the bf16 tolerance of 1e-2 of the fp32 path."""
+    d = dict(DIMS["small"], D=4096, M=64, L=8, A=5, T=3)
+    salt, B = 941, 3
+    wm, _, _ = build_models(d, salt)
+    wm = wm.to(DEV)
+    obs, actions, rewards, continues, noise = observe_inputs(d, salt, B)
+    args = (obs.to(DEV).float() / 255.0, actions.to(DEV), rewards.to(DEV), continues.to(DEV))
+    noise = {k: v.to(DEV) for k, v in noise.items()}
+    l32, i32 = wm.loss(*args, noise=noise)
+    l32.backward()
+    g32 = {n: p.grad.clone() for n, p in wm.named_parameters() if p.grad is not None}
+    wm.zero_grad(set_to_none=True)
+    wm.observe_precision = "bf16"
+    l16, i16 = wm.loss(*args, noise=noise)
+    l16.backward()
+    assert torch.equal(i16["z"].argmax(-1), i32["z"].argmax(-1))
+    assert not torch.equal(i16["h"], i32["h"])      # the other kernels ran
+    for key in ("h", "post_logits", "prior_logits"):
+        assert rel_err(i16[key].detach().cpu(), i32[key].detach().cpu()) < 1e-2, key
+    assert rel_err(l16.detach().cpu(), l32.detach().cpu()) < 1e-2
+    for n, p in wm.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad.cpu(), g32[n].cpu()) < 3e-2, n
