@@ -241,6 +241,55 @@ def measure_acting(learner, device, rng, steps=300):
     return out
 
 
+def measure_scaled_model(device, steps=4):
+    """BASELINE config 5 on one GPU: D = 4096, 32 x 32 categorical latent, 64 x 64 frames; random weights and inputs."""
+    from dreamer_amd.actor import Actor
+    from dreamer_amd.critic import Critic
+    from dreamer_amd.imagine import ImagineEngine
+    from dreamer_amd.world_model import WorldModel, WorldModelState
+    D, L, K, M, A, B, T, H = 4096, 32, 32, 512, 6, 16, 64, 15
+    torch.manual_seed(0)
+    wm = WorldModel((3, 64, 64), A, num_latents=L, classes_per_latent=K, hidden_size=D, mlp_hidden_units=M).to(device).train()
+    actor = Actor(D + L * K, A, M, 2).to(device)
+    critic = Critic(D + L * K, M, 2).to(device)
+    g = torch.Generator().manual_seed(1)
+    obs = torch.rand(B, T, 3, 64, 64, generator=g).to(device)
+    actions = torch.randint(0, A, (B, T), generator=g).to(device)
+    rewards = torch.randn(B, T, generator=g).to(device)
+    continues = (torch.rand(B, T, generator=g) > 0.02).to(device)
+
+    def timeit(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps * 1e3
+
+    def update():
+        wm.zero_grad(set_to_none=True)
+        loss, _ = wm.loss(obs, actions, rewards, continues)
+        loss.backward()
+
+    out = {"config": f"D={D}, {L}x{K} latent, mlp {M}, A={A}; world-model loss + backward over {B} x {T} frames; "
+                     f"imagination block H={H}"}
+    for prec in ("f32", "bf16"):
+        wm.observe_precision = prec
+        out[f"wm_loss_backward_ms_{prec}"] = timeit(update)
+    eng = ImagineEngine(wm, actor, critic)
+    for Bi in (16, 1024):
+        h0 = torch.randn(Bi, D, generator=g).tanh().to(device)
+        z0 = torch.nn.functional.one_hot(torch.randint(0, K, (Bi, L), generator=g), K).float().to(device)
+        st = WorldModelState(h=h0, z=z0)
+        for prec in ("f32", "bf16"):
+            ms = timeit(lambda: eng.run(st, H, 0.997, 0.95, repack=False, persistent=True, precision=prec))
+            out[f"imagine_B{Bi}_{prec}_ms_per_block"] = ms
+            out[f"imagine_B{Bi}_{prec}_steps_per_s"] = Bi * H / ms * 1e3
+    return out
+
+
 def progress(msg):
     """One line on stderr per phase (stdout carries only the JSON line)."""
     print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
@@ -411,6 +460,16 @@ def main():
                               "rows": bench_stream.run(large_only=True, device=str(device), verbose=False)}
         except Exception as e:
             stream_kernels = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+
+    # the scaled model (recurrent width 4096, 32 x 32 latent): world-model loss + backward over the 16 x 64 batch and
+    # the imagination block, fp32 products against bf16 matrix inputs read from bf16 weight images (one GPU, rank 0)
+    if rank == 0 and world == 1 and args.workload == "imagine16" and not args.no_extras:
+        try:
+            extras["c5"] = measure_scaled_model(device)
+            progress("scaled model (D=4096): " + ", ".join(f"{k} {v:.2f}" for k, v in extras["c5"].items() if isinstance(v, float)))
+        except Exception as e:
+            extras["c5"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
 
     def emit(train):

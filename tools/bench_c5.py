@@ -1,0 +1,58 @@
+"""Diagnostic: the scaled model (recurrent width 4096, 32 x 32 categorical latent) on one GPU: world-model loss + backward
+over a 16 x 64 batch and the imagination block, fp32 products against bf16 matrix inputs."""
+import json, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dreamer_amd.actor import Actor
+from dreamer_amd.critic import Critic
+from dreamer_amd.imagine import ImagineEngine
+from dreamer_amd.world_model import WorldModel, WorldModelState
+
+dev = torch.device("cuda:0")
+D, L, K, M, A = 4096, 32, 32, 512, 6
+torch.manual_seed(0)
+wm = WorldModel((3, 64, 64), A, num_latents=L, classes_per_latent=K, hidden_size=D, mlp_hidden_units=M).to(dev).train()
+actor = Actor(D + L * K, A, M, 2).to(dev)
+critic = Critic(D + L * K, M, 2).to(dev)
+B, T = 16, 64
+g = torch.Generator().manual_seed(1)
+obs = torch.rand(B, T, 3, 64, 64, generator=g).to(dev)
+actions = torch.randint(0, A, (B, T), generator=g).to(dev)
+rewards = torch.randn(B, T, generator=g).to(dev)
+continues = (torch.rand(B, T, generator=g) > 0.02).to(dev)
+out = {}
+
+
+def timeit(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+def update():
+    wm.zero_grad(set_to_none=True)
+    loss, _ = wm.loss(obs, actions, rewards, continues)
+    loss.backward()
+
+
+for prec in ("f32", "bf16"):
+    wm.observe_precision = prec
+    out[f"wm_loss_backward_ms_16x64_{prec}"] = timeit(update, 5)
+    print(prec, "world-model loss + backward: %.2f ms" % out[f"wm_loss_backward_ms_16x64_{prec}"], flush=True)
+eng = ImagineEngine(wm, actor, critic)
+for Bi in (16, 1024):
+    h0 = torch.randn(Bi, D, generator=g).tanh().to(dev)
+    z0 = torch.nn.functional.one_hot(torch.randint(0, K, (Bi, L), generator=g), K).float().to(dev)
+    st = WorldModelState(h=h0, z=z0)
+    for prec in ("f32", "bf16"):
+        ms = timeit(lambda: eng.run(st, 15, 0.997, 0.95, repack=False, persistent=True, precision=prec), 5)
+        out[f"imagine_ms_B{Bi}_{prec}"] = ms
+        print(f"imagine B={Bi} {prec}: {ms:.2f} ms per block = {Bi * 15 / ms * 1e3:.0f} steps/s", flush=True)
+print(json.dumps(out))
