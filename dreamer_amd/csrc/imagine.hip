@@ -548,6 +548,7 @@ struct GatherJob {
     const float* base; int64_t ldb;     // row stride of base (0: one vector for every row)
     float* out; int64_t ldo;
     int N, cw;                          // columns, columns per slice (multiple of 4)
+    float* stats = nullptr;             // or: (rows, slices) x (sum, sum of squares) of the out values of the slice
 };
 struct SampleGatherArgs {
     SampleRowsArgs s;                   // logits == nullptr: no draw, z = forced
@@ -635,11 +636,23 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
         const GatherJob& J = P.g[gi];
         const int lpp = 256 / (J.cw >> 2);
         const int n = slice * J.cw + tid;
+        float a = 0.f;
         if (tid < J.cw && n < J.N) {
-            float a = J.base[(int64_t)b * J.ldb + n];
+            a = J.base[(int64_t)b * J.ldb + n];
             const int live = lpp < S.L ? lpp : S.L;
             for (int i = 0; i < live; ++i) a += s_red[gi][i * J.cw + tid];
             J.out[(int64_t)b * J.ldo + n] = a;
+        }
+        if (J.stats != nullptr) {           // uniform: every thread takes part in the sums
+            float st[2] = {a, a * a};
+            all_sum64<2>(st);
+            __syncthreads();                // s_red[gi] has been read by every thread of this pass
+            if ((tid & 63) == 0) { s_red[gi][(tid >> 6) * 2] = st[0]; s_red[gi][(tid >> 6) * 2 + 1] = st[1]; }
+            __syncthreads();
+            if (tid == 0)
+                *reinterpret_cast<float2*>(J.stats + ((int64_t)b * gridDim.x + slice) * 2) =
+                    make_float2((s_red[gi][0] + s_red[gi][2]) + (s_red[gi][4] + s_red[gi][6]),
+                                (s_red[gi][1] + s_red[gi][3]) + (s_red[gi][5] + s_red[gi][7]));
         }
     }
 }
@@ -692,7 +705,7 @@ static int cu_count() {
     return cached[dev];
 }
 
-int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
+int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                hipStream_t stream, int precision) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
     BigLaunch L{};
@@ -708,11 +721,19 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
         const ProblemSpec& q = specs[i];
         DRM_REQUIRE(q.X && q.W && q.Y && q.K >= 32 && q.K % 32 == 0 && q.N >= 1, DRM_EINVAL, "bad big problem");
         DRM_REQUIRE(aligned16(q.X) && aligned16(q.W) && q.ldx % 4 == 0 && q.ldw % 4 == 0, DRM_EINVAL, "misaligned operand");
-        DRM_REQUIRE(!q.ln_g && !q.add && !q.rowscale, DRM_EINVAL, "large-row GEMM takes activated inputs");
+        DRM_REQUIRE(!q.add && !q.rowscale, DRM_EINVAL, "large-row GEMM: no add / row-scale epilogue");
+        DRM_REQUIRE(!q.ln_g || (precision == 0 && q.ln_b && q.stats_in && q.parts_in >= 1 && q.parts_in <= 16), DRM_EINVAL,
+                    "large-row GEMM: LayerNorm on load needs the fp32 form and the row statistics (1..16 parts)");
+        DRM_REQUIRE(!q.stats_out || precision == 0, DRM_EINVAL, "large-row GEMM: row statistics come from the fp32 form only");
         DRM_REQUIRE(!q.tab || zidx, DRM_EINVAL, "gather table without indices");
         BigProblem& p = L.p[i];
         p.X = q.X; p.ldx = q.ldx; p.W = q.W; p.ldw = q.ldw; p.bias = q.bias; p.tab = q.tab; p.ldt = q.ldt;
         p.Y = q.Y; p.ldy = q.ldy; p.N = q.N; p.K = q.K; p.tile_begin = tiles;
+        p.ln_g = q.ln_g; p.ln_b = q.ln_b; p.stats_in = q.stats_in; p.parts_in = q.parts_in; p.stats_out = q.stats_out;
+        // slices per row of the statistics: 32 columns per accumulator column block when stored from the accumulators,
+        // one per column tile through LDS (problems with a table)
+        p.parts_out = q.stats_out ? (q.tab ? (q.N + bn - 1) / bn : (q.N + bn / 2 - 1) / (bn / 2)) : 0;
+        specs[i].parts_out = p.parts_out;
         tiles += (q.N + bn - 1) / bn;
         const double n = q.N, k = q.K, m = M;
         fl += 2.0 * m * n * k + (q.tab ? (double)latents * m * n : 0.0);
@@ -738,10 +759,14 @@ int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int
         const int64_t ntiles = (int64_t)grid.x * grid.y;
         bool walk = std::getenv("DRM_NO_TILE_WALK") == nullptr;
         for (int i = 0; i < np; ++i) walk = walk && specs[i].tab == nullptr && (specs[i].K / BIG_BK) % 2 == 0 && specs[i].K / BIG_BK >= 4;
-        const int64_t resident = (int64_t)cu_count() * (narrow ? 4 : 2);
+        const int64_t resident = (int64_t)cu_count() * 2;
         const unsigned g = (unsigned)(walk && ntiles > resident ? resident : ntiles);
-        if (narrow) k_linear_big<1><<<dim3(g), dim3(256), 0, stream>>>(L);
-        else k_linear_big<2><<<dim3(g), dim3(256), 0, stream>>>(L);
+        bool any_ln = false;
+        for (int i = 0; i < np; ++i) any_ln = any_ln || specs[i].ln_g != nullptr || specs[i].stats_out != nullptr;
+        if (narrow && any_ln) k_linear_big<1, true><<<dim3(g), dim3(256), 0, stream>>>(L);
+        else if (narrow) k_linear_big<1, false><<<dim3(g), dim3(256), 0, stream>>>(L);
+        else if (any_ln) k_linear_big<2, true><<<dim3(g), dim3(256), 0, stream>>>(L);
+        else k_linear_big<2, false><<<dim3(g), dim3(256), 0, stream>>>(L);
     }
     DRM_LAUNCH_CHECK();
     return DRM_OK;
@@ -792,6 +817,7 @@ static PackLayout pack_layout(const drm_dims& d) {
 
 struct WsLayout {
     size_t a_pre[2], x, gh, d_pre[2], head[3][2], critic_logits, gi, logits, act[3], a1h, xz, split, split_floats, total;   // offsets in floats
+    size_t st_a[2], st_d[2], st_h[3][2];   // row statistics (32 floats per row) of the fp32 large-row path
 };
 constexpr int BIG_MIN_ROWS = 256;   // from this many trajectories on, the MFMA-bound large-row kernels are used
 static WsLayout ws_layout(const drm_dims& d, int B, int H) {
@@ -820,8 +846,14 @@ static WsLayout ws_layout(const drm_dims& d, int B, int H) {
     if (B <= SKINNY_MAX_ROWS && !wide) {
         w.gi = take((size_t)B * 3 * d.D);
         w.logits = take((size_t)B * d.L * d.K);
+    }
+    if (!wide && (B <= SKINNY_MAX_ROWS || B >= BIG_MIN_ROWS)) {
         w.a1h = take((size_t)B * d.M);
         w.xz = take((size_t)B * d.D);
+        if (B >= BIG_MIN_ROWS) {
+            for (int i = 0; i < 2; ++i) { w.st_a[i] = take((size_t)B * 32); w.st_d[i] = take((size_t)B * 32); }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) w.st_h[i][j] = take(rows * 32);
+        }
     }
     w.total = o;
     return w;
@@ -969,8 +1001,17 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
         big_image_cache_begin(ws + wl.split, wl.split_floats * sizeof(float), prec == 2 ? 3 : 1);
 
     const bool few = B <= SKINNY_MAX_ROWS && !wide;
-    if (few) {
-        // ---- few-row path: every layer is cut into ~256 workgroups; the draw of z and the one-hot
+    // fp32 products at many rows take the same launch sequence with the large-row kernel in place of the few-row one:
+    // LayerNorm + SiLU applied by the consumer while it loads (row statistics left behind by the producer)
+    const bool fused = big && !wide && prec == 0 && std::getenv("DRM_NO_FUSED_STEP") == nullptr;
+    auto lin = [&](ProblemSpec* p, int np) -> int {
+        return few ? launch_skinny(p, np, B, s) : launch_big(p, np, B, nullptr, 0, 0, 0, s, 0);
+    };
+    float* st_a[2] = {fused ? ws + wl.st_a[0] : nullptr, fused ? ws + wl.st_a[1] : nullptr};
+    float* st_d[2] = {fused ? ws + wl.st_d[0] : nullptr, fused ? ws + wl.st_d[1] : nullptr};
+    int parts_a[2] = {0, 0}, parts_d[2] = {0, 0};
+    if (few || fused) {
+        // ---- step-wise path.  Few rows: every layer is cut into ~256 workgroups; the draw of z and the one-hot
         // tables it selects (actor layer 1, GRU input) share one launch
         const int last_a = w->actor.n_layers - 1, last_d = w->dyn.n_layers - 1;
         auto sample_gather = [&](int t, bool draw, bool gather) -> int {
@@ -992,10 +1033,12 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                 // columns per slice so that B x slices is about the number of CUs
                 const int nmax = M > D ? M : D;
                 int cw = 4;
-                while (cw < 64 && (int64_t)B * ((nmax + cw - 1) / cw) > 320) cw *= 2;
+                while (cw < (fused ? 256 : 64) && (int64_t)B * ((nmax + cw - 1) / cw) > 320) cw *= 2;
                 slices = (nmax + cw - 1) / cw;
                 a.ng = 2;
                 a.g[0] = GatherJob{pack + pl.actor_zT, M, ws + wl.a1h, M, ws + wl.a_pre[0], M, M, cw};
+                a.g[0].stats = st_a[0];       // the consumer of a_pre[0] (actor layer 2) normalises on load
+                parts_a[0] = slices;
                 a.g[1] = GatherJob{pack + pl.lin_zT, D, w->lin_b, 0, ws + wl.xz, D, D, cw};
             }
             ProfScope prof(PC_SAMPLE, s, (draw ? 40.0 * B * LK : 0.0) + (gather ? (double)B * L * (M + D) : 0.0),
@@ -1009,7 +1052,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             ProblemSpec p[2] = {
                 {io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D},
                 {io->h0, D, nullptr, nullptr, w->actor.w[0], S, w->actor.b[0], nullptr, 0, ws + wl.a1h, M, M, D}};
-            if (int rc = launch_skinny(p, 2, B, s)) return rc;
+            if (int rc = lin(p, 2)) return rc;
             if (int rc = sample_gather(0, false, true)) return rc;
         }
         for (int t = 0; t < H; ++t) {
@@ -1018,13 +1061,17 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             // policy MLP; the action-free part of the GRU input product rides along with its first launch
             const ProblemSpec giz{ws + wl.xz, D, nullptr, nullptr, w->gru_w_ih, D, nullptr, nullptr, 0, ws + wl.gi, 3 * D, 3 * D, D};
             if (last_a == 0) {
-                if (int rc = launch_skinny(&giz, 1, B, s)) return rc;
+                ProblemSpec p = giz;
+                if (int rc = lin(&p, 1)) return rc;
             }
             for (int i = 1; i <= last_a; ++i) {
                 ProblemSpec p[2] = {{ws + wl.a_pre[(i - 1) & 1], M, w->actor.ln_g[i - 1], w->actor.ln_b[i - 1], w->actor.w[i], M,
                                      w->actor.b[i], nullptr, 0, ws + wl.a_pre[i & 1], M, M, M},
                                     giz};
-                if (int rc = launch_skinny(p, i == 1 ? 2 : 1, B, s)) return rc;
+                p[0].stats_in = st_a[(i - 1) & 1]; p[0].parts_in = parts_a[(i - 1) & 1];
+                p[0].stats_out = i < last_a ? st_a[i & 1] : nullptr;      // the last layer's consumer normalises by itself
+                if (int rc = lin(p, i == 1 ? 2 : 1)) return rc;
+                parts_a[i & 1] = p[0].parts_out;
             }
             float* h_new = io->h_out + (size_t)t * D;
             {
@@ -1052,17 +1099,22 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                     {h_new, (int64_t)H * D, nullptr, nullptr, w->dyn.w[0], D, w->dyn.b[0], nullptr, 0, ws + wl.d_pre[0], M, M, D},
                     {h_new, (int64_t)H * D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D},
                     {h_new, (int64_t)H * D, nullptr, nullptr, w->actor.w[0], S, w->actor.b[0], nullptr, 0, ws + wl.a1h, M, M, D}};
-                if (int rc = launch_skinny(p, more ? 3 : 1, B, s)) return rc;
+                p[0].stats_out = st_d[0];
+                if (int rc = lin(p, more ? 3 : 1)) return rc;
+                parts_d[0] = p[0].parts_out;
             }
             for (int i = 1; i <= last_d; ++i) {
                 ProblemSpec p{ws + wl.d_pre[(i - 1) & 1], M, w->dyn.ln_g[i - 1], w->dyn.ln_b[i - 1], w->dyn.w[i], M, w->dyn.b[i],
                               nullptr, 0, ws + wl.d_pre[i & 1], M, M, M};
-                if (int rc = launch_skinny(&p, 1, B, s)) return rc;
+                p.stats_in = st_d[(i - 1) & 1]; p.parts_in = parts_d[(i - 1) & 1]; p.stats_out = st_d[i & 1];
+                if (int rc = lin(&p, 1)) return rc;
+                parts_d[i & 1] = p.parts_out;
             }
             {
                 ProblemSpec p{ws + wl.d_pre[last_d & 1], M, w->dyn.ln_g[last_d], w->dyn.ln_b[last_d], w->dyn.head_w, M,
                               w->dyn.head_b, nullptr, 0, ws + wl.logits, LK, LK, M};
-                if (int rc = launch_skinny(&p, 1, B, s)) return rc;
+                p.stats_in = st_d[last_d & 1]; p.parts_in = parts_d[last_d & 1];
+                if (int rc = lin(&p, 1)) return rc;
             }
             if (int rc = sample_gather(t, true, t + 1 < H)) return rc;
         }
@@ -1179,23 +1231,41 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     const size_t tabs[3] = {pl.rew_zT, pl.cont_zT, pl.critic_zT};
     int depth_max = 0;
     for (int i = 0; i < 3; ++i) depth_max = heads[i]->n_layers > depth_max ? heads[i]->n_layers : depth_max;
+    float* st_h[3][2];
+    int parts_h[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) st_h[i][j] = fused ? ws + wl.st_h[i][j] : nullptr;
     for (int dep = 0; dep <= depth_max; ++dep) {
         ProblemSpec p[3];
+        int who[3];
         int np = 0;
         for (int i = 0; i < 3; ++i) {
             const drm_mlp& m = *heads[i];
+            // a later matrix product normalises this output while loading it (the scalar finish kernel normalises by itself)
+            const bool feeds_product = dep + 1 < m.n_layers || (i == 2 && dep + 1 == m.n_layers);
             if (dep == 0) {
-                p[np++] = ProblemSpec{io->h_out, D, nullptr, nullptr, m.w[0], S, m.b[0], pack + tabs[i], M, ws + wl.head[i][0], M, M, D};
+                p[np] = ProblemSpec{io->h_out, D, nullptr, nullptr, m.w[0], S, m.b[0], pack + tabs[i], M, ws + wl.head[i][0], M, M, D};
             } else if (dep < m.n_layers) {
-                p[np++] = ProblemSpec{ws + wl.head[i][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.w[dep], M, m.b[dep],
-                                      nullptr, 0, ws + wl.head[i][dep & 1], M, M, M};
+                p[np] = ProblemSpec{ws + wl.head[i][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.w[dep], M, m.b[dep],
+                                    nullptr, 0, ws + wl.head[i][dep & 1], M, M, M};
             } else if (dep == m.n_layers && i == 2) {  // critic bucket logits
-                p[np++] = ProblemSpec{ws + wl.head[2][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.head_w, M, m.head_b,
-                                      nullptr, 0, ws + wl.critic_logits, 256, d.NB, M};
+                p[np] = ProblemSpec{ws + wl.head[2][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.head_w, M, m.head_b,
+                                    nullptr, 0, ws + wl.critic_logits, 256, d.NB, M};
+            } else {
+                continue;
             }
+            if (dep > 0) { p[np].stats_in = st_h[i][(dep - 1) & 1]; p[np].parts_in = parts_h[i][(dep - 1) & 1]; }
+            if (dep < m.n_layers && feeds_product) p[np].stats_out = st_h[i][dep & 1];
+            who[np++] = i;
         }
         if (np == 0) continue;
-        if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s, prec)) return rc;
+        if (fused) {
+            if (int rc = launch_big(p, np, rows, io->zidx_out, L, L, d.K, s, 0)) return rc;
+            for (int q = 0; q < np; ++q)
+                if (p[q].stats_out) parts_h[who[q]][dep & 1] = p[q].parts_out;
+        } else {
+            for (int q = 0; q < np; ++q) { p[q].stats_in = nullptr; p[q].parts_in = 0; p[q].stats_out = nullptr; }
+            if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s, prec)) return rc;
+        }
     }
     {
         ScalarHeadsArgs a{};

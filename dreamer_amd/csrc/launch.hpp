@@ -15,6 +15,11 @@ struct ProblemSpec {
     float* Y; int64_t ldy; int N, K;
     const float* add = nullptr; int64_t ldadd = 0;          // Y += add[m][n]
     const float* rowscale = nullptr; int64_t ldrs = 0;      // Y *= rowscale[m]
+    // large-row fp32 launches only: partial row sums (sum, sum of squares) per slice of the row.  stats_in: those of
+    // the X rows, which LayerNorm (ln_g / ln_b) needs; stats_out: where to leave those of the Y rows (launch_big
+    // fills parts_out with the number of slices per row it wrote)
+    const float* stats_in = nullptr; int parts_in = 0;
+    float* stats_out = nullptr; int parts_out = 0;
 };
 
 static inline int check_problem(const ProblemSpec& s) {
@@ -168,7 +173,7 @@ static inline int launch_stbwd(const ProblemSpec& spec, int M, int latents, cons
 }
 
 // large-row MFMA GEMM (defined next to its kernel in imagine.hip)
-int launch_big(const ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
+int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                hipStream_t stream, int precision = 0);
 // bf16 images of the weights the large-row launches of the calling thread read, until ..._end(): `base` (16-byte
 // aligned, `bytes` long) receives them on first use; planes = 3 serves precision 2, planes = 1 precision 1

@@ -26,6 +26,13 @@ struct BigProblem {
     float* Y; int64_t ldy;
     int N, K;
     int tile_begin;                  // first blockIdx.x (column tile) of this problem
+    // fp32 form only.  LayerNorm + SiLU of the X rows on their way into LDS (the consumer normalises), with the row
+    // statistics taken from partial sums the producer of X left behind: stats_in[row][part] = (sum, sum of squares)
+    // over a slice of the row, parts_in <= 16 slices.  stats_out: the same for the Y rows this problem writes
+    // (slices of 32 NT columns when stored from the accumulators, of 64 NT columns through LDS).
+    const float* ln_g = nullptr; const float* ln_b = nullptr;
+    const float* stats_in = nullptr; int parts_in = 0;
+    float* stats_out = nullptr; int parts_out = 0;
     const uint16_t* Ws = nullptr;    // W as bf16 images [planes][N][K] made by k_split_planes (split form: 3 planes; bf16 form: 1), or nullptr
 };
 
@@ -38,6 +45,31 @@ struct BigLaunch {
 
 constexpr int BIG_BM = 64, BIG_BN = 128, BIG_BN64 = 64, BIG_BK = 32, BIG_LD = 36;
 
+// Sum over the 64 lanes of a wave of each of 32 per-lane values with a butterfly in which the number of live values
+// halves per level (31 exchanges, then one across the wave halves); lane l ends up with the total of value number
+// bit-reverse5(l & 31).
+__device__ __forceinline__ float halving_sum32_big(float (&v)[32], int lane) {
+#define DRM_HALVE_BIG(j)                                                    \
+    {                                                                       \
+        constexpr int n = 32 >> (j);                                        \
+        const bool up = (lane & (1 << (j))) != 0;                           \
+        _Pragma("unroll") for (int i = 0; i < n / 2; ++i) {                 \
+            const float keep = up ? v[i + n / 2] : v[i];                    \
+            const float send = up ? v[i] : v[i + n / 2];                    \
+            v[i] = keep + xor_lane<(1 << (j))>(send);                       \
+        }                                                                   \
+    }
+    DRM_HALVE_BIG(0) DRM_HALVE_BIG(1) DRM_HALVE_BIG(2) DRM_HALVE_BIG(3) DRM_HALVE_BIG(4)
+#undef DRM_HALVE_BIG
+    return v[0] + xor_lane<32>(v[0]);
+}
+
+// x * sigmoid(x) from the hardware's exp2 and reciprocal (each within 1 ulp): 6 instructions where the IEEE division
+// sequence takes about 30; used where the activation runs between matrix instructions
+__device__ __forceinline__ float big_silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+
 // Epilogue shared by the large-row kernels: the 64 x BN output tile lies in LDS (row stride BN + 4 words), every thread
 // owns 4 consecutive columns of a row: + bias, + one-hot table rows (16-byte reads), 16-byte coalesced stores.
 template <int BN>
@@ -46,10 +78,10 @@ __device__ __forceinline__ void big_epilogue(const BigLaunch& L, const BigProble
     constexpr int TPR = BN / 4;                  // threads per output row
     const int c4 = (tid % TPR) * 4;
     const int n = n0 + c4;
-    if (n >= P.N) return;
+    const bool live = n < P.N;                   // (no early return: the row sums below are taken over whole lane groups)
     const bool vec = (n + 3 < P.N) && ((P.ldy & 3) == 0) && ((P.ldt & 3) == 0);
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.bias) {
+    if (P.bias && live) {
         bias.x = P.bias[n];
         if (n + 1 < P.N) bias.y = P.bias[n + 1];
         if (n + 2 < P.N) bias.z = P.bias[n + 2];
@@ -60,7 +92,7 @@ __device__ __forceinline__ void big_epilogue(const BigLaunch& L, const BigProble
         if (m >= L.M) break;
         float4 y = *reinterpret_cast<const float4*>(&sC[r][c4]);
         y.x += bias.x; y.y += bias.y; y.z += bias.z; y.w += bias.w;
-        if (P.tab != nullptr) {
+        if (P.tab != nullptr && live) {
             const uint8_t* zi = L.zidx + (int64_t)m * L.ldz;
             if (vec) {
                 for (int l = 0; l < L.latents; l += 8) {
@@ -84,14 +116,23 @@ __device__ __forceinline__ void big_epilogue(const BigLaunch& L, const BigProble
                 }
             }
         }
-        float* out = P.Y + (int64_t)m * P.ldy + n;
-        if (vec) {
-            *reinterpret_cast<float4*>(out) = y;
-        } else {
-            out[0] = y.x;
-            if (n + 1 < P.N) out[1] = y.y;
-            if (n + 2 < P.N) out[2] = y.z;
-            if (n + 3 < P.N) out[3] = y.w;
+        if (live) {
+            float* out = P.Y + (int64_t)m * P.ldy + n;
+            if (vec) {
+                *reinterpret_cast<float4*>(out) = y;
+            } else {
+                out[0] = y.x;
+                if (n + 1 < P.N) out[1] = y.y;
+                if (n + 2 < P.N) out[2] = y.z;
+                if (n + 3 < P.N) out[3] = y.w;
+            }
+        }
+        if (P.stats_out != nullptr) {       // partial row sums over this tile's columns (uniform branch)
+            const float v0 = live ? y.x : 0.f, v1 = n + 1 < P.N ? y.y : 0.f, v2 = n + 2 < P.N ? y.z : 0.f, v3 = n + 3 < P.N ? y.w : 0.f;
+            const float sm = group_sum<TPR>((v0 + v1) + (v2 + v3));
+            const float sq = group_sum<TPR>((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+            if (tid % TPR == 0)
+                *reinterpret_cast<float2*>(P.stats_out + ((int64_t)m * P.parts_out + n0 / BN) * 2) = make_float2(sm, sq);
         }
     }
 }
@@ -116,7 +157,9 @@ __device__ __forceinline__ void big_epilogue(const BigLaunch& L, const BigProble
 // drain between tiles.  Past the last tile the loads re-read its last step (no branch in the loop: the load counter
 // the compiler waits on stays exact, only the loads a store needs are waited for).  Problems with a one-hot table
 // take the epilogue through LDS and are launched one tile per workgroup.
-template <int NT>
+// LNT: some problem of the launch normalises its X rows on load or leaves row statistics behind (the code for both
+// costs ~50 registers).
+template <int NT, bool LNT>
 __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
     constexpr int BN = 64 * NT, NB = 2 * NT;
     constexpr int STAGE_WORDS = 2 * (BIG_BM + BN) * BIG_LD, TILE_WORDS = BIG_BM * (BN + 4);
@@ -147,7 +190,12 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
     int pin, m0n, n0n, nkn;                               // the same for the next tile of the sequence
     const float* xan[2];
     const float* wbn[NB];
-#define BIG_TILE(tile, PI, M0, N0, NK, XA, WB)                                                        \
+    // LayerNorm + SiLU of the X rows on load: mean / reciprocal deviation of the thread's two staging rows, scale and
+    // shift vectors at the thread's k offset (a valid dummy address when the problem has none)
+    bool ln, lnn;
+    float mu[2], rs[2], mun[2], rsn[2];
+    const float* gp; const float* bp; const float* gpn; const float* bpn;
+#define BIG_TILE(tile, PI, M0, N0, NK, XA, WB, LN, MU, RS, GP, BP)                                    \
     {                                                                                                 \
         const int bx_ = (tile) % L.ntx, by_ = (tile) / L.ntx;                                         \
         PI = 0;                                                                                       \
@@ -156,10 +204,26 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         N0 = (bx_ - Q.tile_begin) * BN; M0 = by_ * BIG_BM; NK = Q.K / BIG_BK;                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) XA[i] = Q.X + (int64_t)min(M0 + srow + 32 * i, L.M - 1) * Q.ldx + skq;  \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) WB[i] = Q.W + (int64_t)min(N0 + srow + 32 * i, Q.N - 1) * Q.ldw + skq; \
+        LN = LNT && Q.ln_g != nullptr;                                                                \
+        GP = LN ? Q.ln_g + skq : XA[0]; BP = LN ? Q.ln_b + skq : XA[0];                               \
+        /* row statistics: the 8 threads of a staging row fetch two parts each (no branch around the loads) */ \
+        const float* st_ = LN ? Q.stats_in : Q.X;                                                     \
+        const int np_ = LN ? Q.parts_in : 1;                                                          \
+        if (LNT) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                      \
+            const int64_t row_ = LN ? (int64_t)min(M0 + srow + 32 * i, L.M - 1) : 0;                  \
+            const int p0_ = (tid & 7) * 2, p1_ = p0_ + 1;                                             \
+            const float2 a_ = *reinterpret_cast<const float2*>(st_ + (row_ * np_ + min(p0_, np_ - 1)) * 2);  \
+            const float2 b_ = *reinterpret_cast<const float2*>(st_ + (row_ * np_ + min(p1_, np_ - 1)) * 2);  \
+            const float sm_ = group_sum<8>((p0_ < np_ ? a_.x : 0.f) + (p1_ < np_ ? b_.x : 0.f));      \
+            const float sq_ = group_sum<8>((p0_ < np_ ? a_.y : 0.f) + (p1_ < np_ ? b_.y : 0.f));      \
+            const float mean_ = sm_ / (float)Q.K;                                                     \
+            MU[i] = mean_; RS[i] = 1.0f / sqrtf(fmaxf(sq_ / (float)Q.K - mean_ * mean_, 0.f) + LN_EPS);  \
+        }                                                                                             \
     }
-    BIG_TILE(tbase + tj, pi, m0, n0, nk, xa, wb)
+    BIG_TILE(tbase + tj, pi, m0, n0, nk, xa, wb, ln, mu, rs, gp, bp)
 
     f32x4 ra0[2], ra1[2], rb0[NB], rb1[NB];            // register stages 0 / 1
+    f32x4 rg0, rg1, rs0, rs1;                          // LayerNorm scale / shift at the stage's k offset
     // operands of K-step `step` of the current tile, or of step - nk of the next tile once step >= nk
 #define BIG_LOAD(S, step)                                                                             \
     {                                                                                                 \
@@ -167,9 +231,24 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         const int ko = (cur_ ? (step) : min((step) - nk, nkn - 1)) * BIG_BK;                          \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) ra##S[i] = *reinterpret_cast<const f32x4*>((cur_ ? xa[i] : xan[i]) + ko);  \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) rb##S[i] = *reinterpret_cast<const f32x4*>((cur_ ? wb[i] : wbn[i]) + ko); \
+        if (LNT) {                                                                                    \
+            rg##S = *reinterpret_cast<const f32x4*>((cur_ ? gp : gpn) + ko);                          \
+            rs##S = *reinterpret_cast<const f32x4*>((cur_ ? bp : bpn) + ko);                          \
+        }                                                                                             \
     }
-#define BIG_STORE(S, buf)                                                                             \
+    // registers -> LDS; `step` is the K-step the stage holds (>= nk: it belongs to the next tile)
+#define BIG_STORE(S, buf, step)                                                                       \
     {                                                                                                 \
+        const bool nx_ = (step) >= nk;                                                                \
+        if (LNT && (nx_ ? lnn : ln)) {                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+                const float m_ = nx_ ? mun[i] : mu[i], r_ = nx_ ? rsn[i] : rs[i];                     \
+                ra##S[i].x = big_silu((ra##S[i].x - m_) * r_ * rg##S.x + rs##S.x);                    \
+                ra##S[i].y = big_silu((ra##S[i].y - m_) * r_ * rg##S.y + rs##S.y);                    \
+                ra##S[i].z = big_silu((ra##S[i].z - m_) * r_ * rg##S.z + rs##S.z);                    \
+                ra##S[i].w = big_silu((ra##S[i].w - m_) * r_ * rg##S.w + rs##S.w);                    \
+            }                                                                                         \
+        }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&sA[buf][srow + 32 * i][skq]) = ra##S[i];  \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&sB[buf][srow + 32 * i][skq]) = rb##S[i]; \
     }
@@ -192,7 +271,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         BIG_FRAG(buf, 3, fd)                                                                          \
         BIG_MMA(fb)                                                                                   \
         BIG_FENCE                                                                                     \
-        BIG_STORE(S, (buf) ^ 1)                                                                       \
+        BIG_STORE(S, (buf) ^ 1, (step) + 1)                                                           \
         BIG_FENCE                                                                                     \
         BIG_MMA(fc)                                                                                   \
         BIG_FENCE                                                                                     \
@@ -212,14 +291,14 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
     STAMP_DECL_AT(blockIdx.x < 48)
     STAMP();
     // the first tile's prologue (the "next tile" of these loads is never reached: nk >= 1)
-    pin = pi; m0n = m0; n0n = n0; nkn = nk;
+    pin = pi; m0n = m0; n0n = n0; nkn = nk; lnn = ln; gpn = gp; bpn = bp;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xan[i] = xa[i];
+    for (int i = 0; i < 2; ++i) { xan[i] = xa[i]; mun[i] = mu[i]; rsn[i] = rs[i]; }
 #pragma unroll
     for (int i = 0; i < NB; ++i) wbn[i] = wb[i];
     BIG_LOAD(0, 0)
     BIG_LOAD(1, 1)
-    BIG_STORE(0, 0)
+    BIG_STORE(0, 0, 0)
     __syncthreads();
     STAMP();
     BIG_LOAD(0, 2)
@@ -230,7 +309,7 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         const BigProblem& P = L.p[pi];
         const bool more = tj + tstride < tlimit;
         // (no branches in the tile set-up: a branch makes the compiler wait for every load in flight)
-        BIG_TILE(tbase + (more ? tj + tstride : tj), pin, m0n, n0n, nkn, xan, wbn)
+        BIG_TILE(tbase + (more ? tj + tstride : tj), pin, m0n, n0n, nkn, xan, wbn, lnn, mun, rsn, gpn, bpn)
         // bias of the lane's output columns, fetched before the K loop
         float bias_lane[NT];
 #pragma unroll
@@ -261,13 +340,43 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = n0 + wn * 32 * NT + 32 * j + li;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] += bias_lane[j];
                 if (n < P.N) {
                     float* out = P.Y + (int64_t)(m0 + wm * 32 + 4 * lh) * P.ldy + n;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int r = (i & 3) + 8 * (i >> 2);
-                        if (m0 + wm * 32 + 4 * lh + r < L.M) out[(int64_t)r * P.ldy] = acc[j][i] + bias_lane[j];
+                        if (m0 + wm * 32 + 4 * lh + r < L.M) out[(int64_t)r * P.ldy] = acc[j][i];
                     }
+                }
+            }
+            if (LNT && P.stats_out != nullptr) {
+                // partial row sums over the wave's 32 NT columns: 16 rows per lane half; per quantity one 32-value
+                // halving butterfly over the wave (each half contributes zeros in the other half's slots)
+                int idx = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) idx |= ((lane >> j) & 1) << (4 - j);
+                const int half = idx >> 4, irow = idx & 15;
+                const int m = m0 + wm * 32 + (irow & 3) + 8 * (irow >> 2) + 4 * half;
+                const int part = (n0 + wn * 32 * NT) / (32 * NT);
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    float v[32];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const float y = (n0 + wn * 32 * NT + 32 * j + li) < P.N ? acc[j][i] : 0.f;
+                            t += which == 0 ? y : y * y;
+                        }
+                        v[i] = lh == 0 ? t : 0.f;
+                        v[16 + i] = lh == 1 ? t : 0.f;
+                    }
+                    const float tot = halving_sum32_big(v, lane);
+                    if (lane < 32 && m < L.M && part < P.parts_out)
+                        P.stats_out[((int64_t)m * P.parts_out + part) * 2 + which] = tot;
                 }
             }
         } else {
@@ -286,9 +395,9 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         STAMP();
         if (!more) break;
         tj += tstride;
-        pi = pin; m0 = m0n; n0 = n0n; nk = nkn;
+        pi = pin; m0 = m0n; n0 = n0n; nk = nkn; ln = lnn; gp = gpn; bp = bpn;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xa[i] = xan[i];
+        for (int i = 0; i < 2; ++i) { xa[i] = xan[i]; mu[i] = mun[i]; rs[i] = rsn[i]; }
 #pragma unroll
         for (int i = 0; i < NB; ++i) wb[i] = wbn[i];
     }
