@@ -3,6 +3,17 @@
 
 namespace drm {
 
+// Streamed once: these kernels' loads and stores carry the non-temporal hint (nothing they touch is read again
+// soon, so the lines need not displace what the caches hold).
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stnt4(float* p, const float4& v) {
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+}
+
 // ------------------------------------------------------------------------------------------------
 // lambda-return (lib/trainer.py:217-224).  One block owns ROWS consecutive trajectories: their R/C/V
 // values are one contiguous run of ROWS*H floats in each input, moved with 16-byte accesses, four per
@@ -38,7 +49,8 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = min(k0 + u * ROWS + tid, n4 - 1);
-            r[u] = R4[i]; c[u] = C4[i]; v[u] = V4[i];
+            r[u] = ldnt4(reinterpret_cast<const float*>(R4 + i)); c[u] = ldnt4(reinterpret_cast<const float*>(C4 + i));
+            v[u] = ldnt4(reinterpret_cast<const float*>(V4 + i));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
     float4* O4 = reinterpret_cast<float4*>(out + base);
     for (int i = tid; i < n4; i += ROWS) {
         if (HS == H) {
-            O4[i] = reinterpret_cast<const float4*>(sA)[i];
+            stnt4(reinterpret_cast<float*>(O4 + i), reinterpret_cast<const float4*>(sA)[i]);
         } else {
             int rr = (i * 4) / H, t = i * 4 - rr * H;
             float o[4];
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
                 o[j] = sA[rr * HS + t];
                 if (++t == H) { t = 0; ++rr; }
             }
-            O4[i] = make_float4(o[0], o[1], o[2], o[3]);
+            stnt4(reinterpret_cast<float*>(O4 + i), make_float4(o[0], o[1], o[2], o[3]));
         }
     }
     for (int e = n4 * 4 + tid; e < n; e += ROWS) {
@@ -176,17 +188,17 @@ __global__ __launch_bounds__(256) void k_seq_gather(drm_ring ring, const int64_t
     const int tid = threadIdx.x;
     constexpr int U = 4;
     if (obs_f32 == nullptr) {
-        const uint4* s16 = reinterpret_cast<const uint4*>(ring.observations + src * ring.frame_bytes);
-        uint4* d16 = reinterpret_cast<uint4*>(obs_out + frame * ring.frame_bytes);
+        const u32x4s* s16 = reinterpret_cast<const u32x4s*>(ring.observations + src * ring.frame_bytes);
+        u32x4s* d16 = reinterpret_cast<u32x4s*>(obs_out + frame * ring.frame_bytes);
         const int n16 = (int)(ring.frame_bytes >> 4);
         for (int k0 = 0; k0 < n16; k0 += 256 * U) {
-            uint4 v[U];
+            u32x4s v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = s16[min(k0 + u * 256 + tid, n16 - 1)];
+            for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(s16 + min(k0 + u * 256 + tid, n16 - 1));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = k0 + u * 256 + tid;
-                if (i < n16) d16[i] = v[u];
+                if (i < n16) __builtin_nontemporal_store(v[u], d16 + i);
             }
         }
     } else {
@@ -197,14 +209,14 @@ __global__ __launch_bounds__(256) void k_seq_gather(drm_ring ring, const int64_t
         for (int k0 = 0; k0 < n4; k0 += 256 * U) {
             uint32_t w[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) w[u] = s4[min(k0 + u * 256 + tid, n4 - 1)];
+            for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(s4 + min(k0 + u * 256 + tid, n4 - 1));
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = k0 + u * 256 + tid;
                 if (i < n4) {
-                    d4[i] = w[u];
-                    d[i] = make_float4(byte_over_255(w[u] & 0xffu), byte_over_255((w[u] >> 8) & 0xffu),
-                                       byte_over_255((w[u] >> 16) & 0xffu), byte_over_255(w[u] >> 24));
+                    __builtin_nontemporal_store(w[u], d4 + i);
+                    stnt4(reinterpret_cast<float*>(d + i), make_float4(byte_over_255(w[u] & 0xffu), byte_over_255((w[u] >> 8) & 0xffu),
+                                                                         byte_over_255((w[u] >> 16) & 0xffu), byte_over_255(w[u] >> 24)));
                 }
             }
         }
@@ -231,8 +243,8 @@ __global__ __launch_bounds__(256) void k_sample_st(const float* __restrict__ log
     const int sub = threadIdx.x & 7;
     const int64_t stride = (int64_t)gridDim.x * 32;
     for (int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); row < rows; row += stride) {
-        const float4 lg = *reinterpret_cast<const float4*>(logits + row * 32 + sub * 4);
-        const float4 ex = *reinterpret_cast<const float4*>(expo + row * 32 + sub * 4);
+        const float4 lg = ldnt4(logits + row * 32 + sub * 4);
+        const float4 ex = ldnt4(expo + row * 32 + sub * 4);
         const float v[4] = {lg.x, lg.y, lg.z, lg.w};
         const float e[4] = {ex.x, ex.y, ex.z, ex.w};
         const float mx = group_max<8>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
@@ -254,13 +266,12 @@ __global__ __launch_bounds__(256) void k_sample_st(const float* __restrict__ log
         group_argmax<8>(best, bi);
         if (y_out) {
             const float inv = __builtin_amdgcn_rcpf(group_sum<8>((w[0] + w[1]) + (w[2] + w[3])));
-            *reinterpret_cast<float4*>(y_out + row * 32 + sub * 4) = make_float4(w[0] * inv, w[1] * inv, w[2] * inv, w[3] * inv);
+            stnt4(y_out + row * 32 + sub * 4, make_float4(w[0] * inv, w[1] * inv, w[2] * inv, w[3] * inv));
         }
         if (z_out) {
             const int k0 = sub * 4;
-            *reinterpret_cast<float4*>(z_out + row * 32 + k0) =
-                make_float4(bi == k0 ? 1.f : 0.f, bi == k0 + 1 ? 1.f : 0.f, bi == k0 + 2 ? 1.f : 0.f,
-                            bi == k0 + 3 ? 1.f : 0.f);
+            stnt4(z_out + row * 32 + k0, make_float4(bi == k0 ? 1.f : 0.f, bi == k0 + 1 ? 1.f : 0.f, bi == k0 + 2 ? 1.f : 0.f,
+                                                     bi == k0 + 3 ? 1.f : 0.f));
         }
         if (idx_out && sub == 0) idx_out[row] = (uint8_t)bi;
     }
