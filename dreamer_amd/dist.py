@@ -75,7 +75,7 @@ class FlatGrads:
         self.offsets: List[int] = []
         self.static = False
         self.seen = None          # static mode, once gradients were gathered: slots that have received one at least once
-        self.channels_last_kernels = os.environ.get("DRM_TOWER_CHANNELS_LAST", "0") == "1" and any(
+        self.channels_last_kernels = os.environ.get("DRM_TOWER_CHANNELS_LAST", "1") == "1" and any(
             p.is_cuda for p in module.parameters())
         if static:
             self._build_static()
