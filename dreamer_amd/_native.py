@@ -123,6 +123,7 @@ SIGNATURES = {
     "drm_percentile_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_convt_k4s2_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_convt_k4s2_input_grad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]),
     "drm_conv4s2_down": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_up": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int32] * 4),
@@ -318,6 +319,21 @@ def convt_k4s2_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     check(lib().drm_convt_k4s2_forward(x.data_ptr(), weight.data_ptr(), ptr(bias), y.data_ptr(), n, cin, cout, h, w,
                                        stream_ptr(x.device)), "drm_convt_k4s2_forward")
     return y
+
+
+def convt_k4s2_input_grad(grad_y: torch.Tensor, weight: torch.Tensor, channels_last: bool) -> torch.Tensor:
+    """Gradient wrt the input of that layer from the gradient wrt its output (N, Cout, 2H, 2W); the result has the
+    logical shape (N, Cin, H, W), in channels-last memory when asked for (Cin a multiple of 4)."""
+    require_cuda(grad_y, weight)
+    _dense(grad_y, torch.float32, "grad_y"); _dense(weight, torch.float32, "weight")
+    n, cout, ho, wo = grad_y.shape
+    cin = weight.shape[0]
+    channels_last = bool(channels_last) and cin % 4 == 0
+    gx = torch.empty((n, cin, ho // 2, wo // 2), dtype=torch.float32, device=grad_y.device,
+                     memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    check(lib().drm_convt_k4s2_input_grad(grad_y.data_ptr(), weight.data_ptr(), gx.data_ptr(), n, cin, cout, ho // 2, wo // 2,
+                                          1 if channels_last else 0, stream_ptr(grad_y.device)), "drm_convt_k4s2_input_grad")
+    return gx
 
 
 def copy_pair(a_dst: torch.Tensor, a_src: torch.Tensor, b_dst: torch.Tensor, b_src: torch.Tensor) -> None:

@@ -94,7 +94,7 @@ class ReplayBuffer:
         T = self.seq_len
         if self.device.type == "cuda":
             from . import _native
-            st = torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int64)).to(self.device, non_blocking=True)
+            st = self._starts_to_device(np.ascontiguousarray(starts, dtype=np.int64))
             o, a, r, c, f = _native.seq_gather(self.observations, self.actions, self.rewards, self.continues, st, T,
                                                want_f32)
         else:
@@ -105,6 +105,28 @@ class ReplayBuffer:
         if want_f32:
             out["observations_f32"] = f
         return out
+
+    def _starts_to_device(self, starts: np.ndarray) -> torch.Tensor:
+        """Start indices to the device through a small ring of pinned staging rows: a copy from pageable memory would
+        make the host wait until the stream has run everything queued before it (once per update: the host could never
+        queue the next update's launches while the device works on this one)."""
+        n = int(starts.shape[0])
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None or ring[0].shape[1] < n:
+            slots = 16
+            ring = (torch.empty(slots, max(n, 64), dtype=torch.int64, pin_memory=True), [None] * slots, [0])
+            self._pin_ring = ring
+        rows, events, cursor = ring
+        k = cursor[0] % rows.shape[0]
+        cursor[0] += 1
+        if events[k] is not None:
+            events[k].synchronize()          # the copy that last read this row (16 samples ago) has run
+        rows[k, :n].copy_(torch.from_numpy(starts))
+        st = rows[k, :n].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events[k] = ev
+        return st
 
     def sample(self, batch_size: int, want_f32: bool = False) -> Dict[str, torch.Tensor]:
         return self.gather(self.draw_starts(batch_size), want_f32)

@@ -199,11 +199,13 @@ class _ConvBiasFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, transposed, stride, padding):
         ctx.save_for_backward(x, weight)
         ctx.conf = (transposed, stride, padding)
-        if (transposed and weight.shape[1] <= 4 and tuple(weight.shape[2:]) == (4, 4) and tuple(stride) == (2, 2)
-                and tuple(padding) == (1, 1) and x.dtype == torch.float32 and _ConvBiasFn.native_convt and x.is_contiguous()):
-            # few output channels: a stream, served by the library's direct kernel (bias included)
+        ctx.direct = (transposed and weight.shape[1] <= 4 and tuple(weight.shape[2:]) == (4, 4) and tuple(stride) == (2, 2)
+                      and tuple(padding) == (1, 1) and x.dtype == torch.float32 and _ConvBiasFn.native_convt)
+        if ctx.direct and x.is_contiguous():
+            # few output channels: a stream, served by the library's direct kernel (bias included); an input in
+            # channels-last memory takes the backend's routine, which reads that layout faster
             from . import _native as N
-            return N.convt_k4s2_forward(x.contiguous(), weight.contiguous(), bias)
+            return N.convt_k4s2_forward(x, weight.contiguous(), bias)
         if transposed:
             return F.conv_transpose2d(x, weight, bias, stride=stride, padding=padding)
         return F.conv2d(x, weight, bias, stride=stride, padding=padding)
@@ -213,8 +215,16 @@ class _ConvBiasFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         transposed, stride, padding = ctx.conf
         g = g.contiguous()
-        gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1], transposed,
-                                                        [0, 0], 1, [ctx.needs_input_grad[0], True, False])
+        if ctx.direct:
+            # input gradient from the library's stream kernel, in the input's own memory format; the weight gradient
+            # (a reduction over all pixels) from the backend's routine
+            from . import _native as N
+            gx = N.convt_k4s2_input_grad(g, weight.contiguous(), N._is_channels_last(x)) if ctx.needs_input_grad[0] else None
+            _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1], transposed,
+                                                           [0, 0], 1, [False, True, False])
+        else:
+            gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1], transposed,
+                                                            [0, 0], 1, [ctx.needs_input_grad[0], True, False])
         gb = g.view(g.shape[0], g.shape[1], -1).sum(2).sum(0)
         return gx, gw, gb, None, None, None
 

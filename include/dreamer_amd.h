@@ -141,6 +141,11 @@ int drm_percentile_scale(const float* x, int32_t n, double q_lo, double q_hi, do
  * NULL, y (N, Cout, 2H, 2W); all contiguous fp32. */
 int drm_convt_k4s2_forward(const float* x, const float* weight, const float* bias, float* y, int64_t N, int32_t Cin,
                            int32_t Cout, int32_t H, int32_t W, drm_stream_t stream);
+/* Input gradient of that layer (what autograd's backward of lib/world_model.py:298-302 forms for the stage before):
+ * grad_y (N, Cout, 2H, 2W) contiguous -> grad_x (N, Cin, H, W), contiguous or (channels_last != 0, Cin % 4 == 0) in
+ * channels-last memory. */
+int drm_convt_k4s2_input_grad(const float* grad_y, const float* weight, float* grad_x, int64_t N, int32_t Cin, int32_t Cout,
+                              int32_t H, int32_t W, int32_t channels_last, drm_stream_t stream);
 
 /* ---- stride-2 4x4 convolutions of the towers as implicit fp32 MFMA products, channels-last activations ----------
  * nn.Conv2d(cb -> cs, kernel 4, stride 2, padding 1) (lib/world_model.py:94-108) and nn.ConvTranspose2d(cs -> cb, kernel 4,

@@ -41,3 +41,22 @@ def test_decoder_with_native_last_stage_matches_torch(monkeypatch):
     assert rel(out, ref) < 1e-5
     for (name, _), a, r in zip(dec.named_parameters(), g_out, g_ref):
         assert rel(a, r) < 2e-4, name
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(64, 32, 3, 32, 32), (3, 32, 1, 4, 4), (2, 32, 4, 7, 9), (5, 32, 2, 1, 1), (4, 5, 3, 6, 5), (2, 8, 3, 5, 6)])
+def test_input_gradient_matches_torch_in_both_memory_formats(n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(7 * n + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cin, cout, 4, 4, generator=g) * 0.1).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    gy = torch.randn(n, cout, 2 * h, 2 * w, generator=g).to(DEV)
+    xd = x.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xd, wt.double(), b.double(), stride=2, padding=1)
+    ref.backward(gy.double())
+    tol = lambda r: 1e-5 * max(float(r.abs().max()), 1.0)
+    for cl in (False, True):
+        gx = N.convt_k4s2_input_grad(gy, wt, cl)
+        assert gx.shape == x.shape
+        if cl and cin % 4 == 0 and n * h * w > 1 and cin > 1:
+            assert gx.is_contiguous(memory_format=torch.channels_last)
+        assert float((gx.double() - xd.grad).abs().max()) < tol(xd.grad)
