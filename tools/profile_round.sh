@@ -13,9 +13,9 @@ export TMPDIR=/tmp
 stats() {  # name, bench args...
     local name=$1; shift
     # the same command without the profiler first: its JSON line is the one to quote (a kernel trace slows short kernels)
-    timeout -k 10 300 python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --train-steps 0 "$@" > "$out/$name.clean.bench.json" 2> /dev/null
+    timeout -k 10 300 python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 "$@" > "$out/$name.clean.bench.json" 2> /dev/null
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/$name" -o "$name" --output-format csv -- \
-        python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --train-steps 0 "$@" > "$out/$name.bench.json" 2> "$out/$name.err"
+        python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 "$@" > "$out/$name.bench.json" 2> "$out/$name.err"
     python3 "$root/tools/prof_summary.py" "$out/$name" 30 > "$out/$name.stats.txt"
     find "$out/$name" -name '*kernel_trace.csv' -delete
 }
@@ -23,7 +23,7 @@ stats() {  # name, bench args...
 pmc() {  # name, counter, bench args...
     local name=$1; local ctr=$2; shift; shift
     timeout -s KILL 200 rocprofv3 --pmc "$ctr" -d "$out/$name.$ctr" -o "$name" --output-format csv -- \
-        python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --train-steps 0 --profile-steps 0 "$@" > /dev/null 2> "$out/$name.$ctr.err"
+        python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 --profile-steps 0 "$@" > /dev/null 2> "$out/$name.$ctr.err"
     python3 "$root/tools/pmc_summary.py" "$out/$name.$ctr" "$ctr" > "$out/$name.$ctr.txt"
     rm -rf "$out/$name.$ctr"
 }
