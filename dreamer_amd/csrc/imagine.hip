@@ -820,6 +820,7 @@ struct WsLayout {
     size_t st_a[2], st_d[2], st_h[3][2];   // row statistics (32 floats per row) of the fp32 large-row path
 };
 constexpr int BIG_MIN_ROWS = 256;   // from this many trajectories on, the MFMA-bound large-row kernels are used
+constexpr int TWO_CHAINS_MIN_ROWS = 2048;   // from this many on, two half-batch chains of launches side by side
 static WsLayout ws_layout(const drm_dims& d, int B, int H) {
     WsLayout w{};
     size_t o = 0;
@@ -941,7 +942,15 @@ extern "C" int drm_fused_linear_split(const drm_linear_args* a, drm_stream_t str
 
 extern "C" size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H) {
     if (!dims || check_dims(*dims) != DRM_OK || B < 1 || H < 1) return 0;
-    return ws_layout(*dims, B, H).total * sizeof(float);
+    size_t bytes = ws_layout(*dims, B, H).total * sizeof(float);
+    if (B >= TWO_CHAINS_MIN_ROWS && B % 128 == 0) {      // two chains of B / 2 trajectories, a workspace each
+        for (int n = 2; n <= 8; n *= 2) {
+            if (B % (64 * n) != 0) break;
+            const size_t parts = n * ((ws_layout(*dims, B / n, H).total * sizeof(float) + 255) & ~(size_t)255);
+            bytes = parts > bytes ? parts : bytes;
+        }
+    }
+    return bytes;
 }
 
 extern "C" int drm_fused_linear_f32(const drm_linear_args* a, drm_stream_t stream) {
@@ -968,7 +977,9 @@ static int run_linear(ProblemSpec* p, int np, int M, const uint8_t* zidx, int64_
     return launch_big(p, np, M, zidx, ldz, latents, classes, s, precision);
 }
 
-static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
+// One chain of launches for io->B trajectories.  `nb`: rows of a time step in the two noise tensors (io->B unless the
+// trajectories are a slice of a larger call, whose noise is laid out (H, nb, ...)).
+static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream, int nb) {
     if (int rc = check_weights(*w)) return rc;
     prof_fresh();
     const drm_dims& d = w->dims;
@@ -1019,7 +1030,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             a.s.B = B; a.s.L = L; a.s.log1m_eps = l1m; a.s.log_eps_over_k = lek;
             a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
             if (draw) {
-                a.s.logits = ws + wl.logits; a.s.ldlg = LK; a.s.expo = io->expo_z + (size_t)t * B * LK; a.s.lde = LK;
+                a.s.logits = ws + wl.logits; a.s.ldlg = LK; a.s.expo = io->expo_z + (size_t)t * nb * LK; a.s.lde = LK;
                 a.s.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.s.ldf = (int64_t)H * L;
                 a.s.idx_used = io->zidx_out + (size_t)t * L; a.s.ldu = (int64_t)H * L;
                 a.s.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.s.ldsm = (int64_t)H * L;
@@ -1079,7 +1090,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                 a.pre = ws + wl.a_pre[last_a & 1]; a.ldp = M;
                 a.ln_g = w->actor.ln_g[last_a]; a.ln_b = w->actor.ln_b[last_a];
                 a.head_w = w->actor.head_w; a.head_b = w->actor.head_b; a.M = M; a.A = d.A;
-                a.expo = io->expo_a + (size_t)t * B * d.A; a.lde = d.A;
+                a.expo = io->expo_a + (size_t)t * nb * d.A; a.lde = d.A;
                 a.forced = io->forced_actions ? io->forced_actions + t : nullptr; a.ldf = H;
                 a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_a = d.unimix_eps / (float)d.A;
                 a.gi_z = ws + wl.gi; a.ldgi = 3 * D; a.gi_a = pack + pl.gi_a; a.b_ih = w->gru_b_ih;
@@ -1145,7 +1156,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
             a.pre = ws + wl.a_pre[last & 1]; a.ldp = M;
             a.ln_g = w->actor.ln_g[last]; a.ln_b = w->actor.ln_b[last];
             a.head_w = w->actor.head_w; a.head_b = w->actor.head_b; a.M = M; a.A = d.A;
-            a.expo = io->expo_a + (size_t)t * B * d.A; a.lde = d.A;
+            a.expo = io->expo_a + (size_t)t * nb * d.A; a.lde = d.A;
             a.forced = io->forced_actions ? io->forced_actions + t : nullptr; a.ldf = H;
             a.log1m_eps = l1m; a.log_eps_over_a = lea;
             a.zidx = z_t; a.ldz = ldz; a.latents = L; a.classes = d.K;
@@ -1195,7 +1206,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                           nullptr, 0, ws + wl.logits, LK, LK, M};
             if (int rc = run_linear(&p, 1, B, nullptr, 0, 0, 0, true, act, M, s, prec)) return rc;
             SampleRowsArgs a{};
-            a.logits = ws + wl.logits; a.ldlg = LK; a.expo = io->expo_z + (size_t)t * B * LK; a.lde = LK;
+            a.logits = ws + wl.logits; a.ldlg = LK; a.expo = io->expo_z + (size_t)t * nb * LK; a.lde = LK;
             a.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.ldf = (int64_t)H * L;
             a.idx_used = io->zidx_out + (size_t)t * L; a.ldu = (int64_t)H * L;
             a.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.ldsm = (int64_t)H * L;
@@ -1213,7 +1224,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
                           nullptr, 0, nullptr, 0, LK, M};
             p.Y = ws;  // unused by the sampling epilogue
             SampleEpilogue E{};
-            E.expo = io->expo_z + (size_t)t * B * LK; E.lde = LK;
+            E.expo = io->expo_z + (size_t)t * nb * LK; E.lde = LK;
             E.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; E.ldf = (int64_t)H * L;
             E.idx_used = io->zidx_out + (size_t)t * L; E.ldu = (int64_t)H * L;
             E.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; E.lds_ = (int64_t)H * L;
@@ -1284,6 +1295,76 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
     }
     return drm_lambda_return(io->rewards_out, io->conts_out, io->values_out, io->v_last_out, io->lam_returns_out, B, H,
                              io->gamma, io->lam, stream);
+}
+
+// Many trajectories are independent: from 2048 on the call runs as two chains of launches, one half of the trajectories
+// each, on two streams of the library's own between a fork and a join on the caller's stream (inside a recording the two
+// chains become two branches of the graph).  The launch boundaries, prologues and row kernels of one chain then sit under
+// the matrix products of the other; every kernel and every result is what the single chain gives.
+namespace drm {
+constexpr int MAX_CHAINS = 8;
+struct TwoChains { hipStream_t s[MAX_CHAINS]; hipEvent_t fork, join[MAX_CHAINS]; int dev; };
+static thread_local TwoChains t_chains{{}, nullptr, {}, -1};
+static int chain_count(int B) {
+    const char* e = std::getenv("DRM_CHAINS");
+    int n = e ? atoi(e) : 2;
+    if (n < 2) n = 2;
+    if (n > MAX_CHAINS) n = MAX_CHAINS;
+    while (n > 2 && (B % (64 * n) != 0 || B / n < 512)) n /= 2;
+    return n;
+}
+static bool two_chains_ok(int B) {
+    return B >= TWO_CHAINS_MIN_ROWS && B % 128 == 0 && !prof_on() && std::getenv("DRM_NO_TWO_CHAINS") == nullptr;
+}
+}  // namespace drm
+
+static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
+    if (!two_chains_ok(io->B)) return imagine_enqueue_part(w, io, stream, io->B);
+    if (int rc = check_weights(*w)) return rc;
+    const drm_dims& d = w->dims;
+    const int nch = chain_count(io->B);
+    const int B = io->B, H = io->H, half = B / nch, LK = d.L * d.K;
+    DRM_REQUIRE(H >= 1 && io->workspace && aligned16(io->workspace), DRM_EINVAL, "bad io");
+    const size_t part_bytes = (ws_layout(d, half, H).total * sizeof(float) + 255) & ~(size_t)255;
+    DRM_REQUIRE(io->workspace_bytes >= nch * part_bytes, DRM_EINVAL, "workspace too small: need %zu bytes", nch * part_bytes);
+    int dev = 0;
+    DRM_HIP(hipGetDevice(&dev));
+    TwoChains& c = t_chains;
+    if (c.dev != dev) {
+        for (int i = 0; i < MAX_CHAINS; ++i) {
+            DRM_HIP(hipStreamCreateWithFlags(&c.s[i], hipStreamNonBlocking));
+            DRM_HIP(hipEventCreateWithFlags(&c.join[i], hipEventDisableTiming));
+        }
+        DRM_HIP(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+        c.dev = dev;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DRM_HIP(hipEventRecord(c.fork, s));
+    int rc = DRM_OK;
+    for (int i = 0; i < nch && rc == DRM_OK; ++i) {
+        DRM_HIP(hipStreamWaitEvent(c.s[i], c.fork, 0));
+        const size_t b0 = (size_t)i * half;
+        drm_imagine_io p = *io;
+        p.B = half;
+        p.h0 = io->h0 + b0 * d.D; p.zidx0 = io->zidx0 + b0 * d.L;
+        p.expo_a = io->expo_a + b0 * d.A; p.expo_z = io->expo_z + b0 * LK;
+        if (io->forced_actions) p.forced_actions = io->forced_actions + b0 * H;
+        if (io->forced_zidx) p.forced_zidx = io->forced_zidx + b0 * H * d.L;
+        p.h_out = io->h_out + b0 * H * d.D; p.zidx_out = io->zidx_out + b0 * H * d.L;
+        p.actions_out = io->actions_out + b0 * H;
+        p.rewards_out = io->rewards_out + b0 * H; p.conts_out = io->conts_out + b0 * H; p.values_out = io->values_out + b0 * H;
+        p.v_last_out = io->v_last_out + b0; p.lam_returns_out = io->lam_returns_out + b0 * H;
+        if (io->z_out) p.z_out = io->z_out + b0 * H * LK;
+        if (io->prior_logits_out) p.prior_logits_out = io->prior_logits_out + b0 * H * LK;
+        if (io->actor_logp_out) p.actor_logp_out = io->actor_logp_out + b0 * H * d.A;
+        if (io->actions_sampled_out) p.actions_sampled_out = io->actions_sampled_out + b0 * H;
+        if (io->zidx_sampled_out) p.zidx_sampled_out = io->zidx_sampled_out + b0 * H * d.L;
+        p.workspace = (char*)io->workspace + i * part_bytes; p.workspace_bytes = part_bytes;
+        rc = imagine_enqueue_part(w, &p, (drm_stream_t)c.s[i], B);
+        // joined even after a failure: a recording must not end with a dangling branch
+        if (hipEventRecord(c.join[i], c.s[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.join[i], 0);
+    }
+    return rc;
 }
 
 // ---- optional replay of the whole block as one hipGraph -----------------------------------------

@@ -12,9 +12,11 @@ export TMPDIR=/tmp
 
 stats() {  # name, bench args...
     local name=$1; shift
+    # kernel durations are read per kernel: the large-batch block runs as one chain of launches here (two side by side
+    # would overlap kernels of the two chains in the trace); the .clean.bench.json line is the shipped configuration
     # the same command without the profiler first: its JSON line is the one to quote (a kernel trace slows short kernels)
     timeout -k 10 300 python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 "$@" > "$out/$name.clean.bench.json" 2> /dev/null
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/$name" -o "$name" --output-format csv -- \
+    DRM_NO_TWO_CHAINS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/$name" -o "$name" --output-format csv -- \
         python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 "$@" > "$out/$name.bench.json" 2> "$out/$name.err"
     python3 "$root/tools/prof_summary.py" "$out/$name" 30 > "$out/$name.stats.txt"
     find "$out/$name" -name '*kernel_trace.csv' -delete
@@ -22,7 +24,7 @@ stats() {  # name, bench args...
 
 pmc() {  # name, counter, bench args...
     local name=$1; local ctr=$2; shift; shift
-    timeout -s KILL 200 rocprofv3 --pmc "$ctr" -d "$out/$name.$ctr" -o "$name" --output-format csv -- \
+    DRM_NO_TWO_CHAINS=1 timeout -s KILL 200 rocprofv3 --pmc "$ctr" -d "$out/$name.$ctr" -o "$name" --output-format csv -- \
         python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 --profile-steps 0 "$@" > /dev/null 2> "$out/$name.$ctr.err"
     python3 "$root/tools/pmc_summary.py" "$out/$name.$ctr" "$ctr" > "$out/$name.$ctr.txt"
     rm -rf "$out/$name.$ctr"
