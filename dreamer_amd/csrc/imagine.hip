@@ -298,7 +298,8 @@ __device__ __forceinline__ float2 ld2(const float* p, bool on) {
     return on ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
 }
 
-// M <= 512 and D <= 512 (both even): thread t owns features 2t, 2t+1 and hidden units 2t, 2t+1.
+// M <= 512 (even), any even D: thread t owns features 2t, 2t+1 and hidden units 512 y + 2t, + 1 of slice y = blockIdx.y
+// of the recurrent state (every slice's workgroup evaluates the policy; slice 0 writes the action and its log-probabilities).
 template <int AMAX>
 __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     __shared__ float s_st[4][2];
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     const int wave = tid >> 6, lane = tid & 63;
     STAMP_DECL
     STAMP();
-    const int i0 = 2 * tid;
-    const bool on = i0 < P.M, jn = i0 < P.D;
+    const int i0 = 2 * tid, j0 = blockIdx.y * 512 + 2 * tid;
+    const bool on = i0 < P.M, jn = j0 < P.D, first = blockIdx.y == 0;
     const int D = P.D;
     // ---- loads that do not depend on the action
     const float* pre = P.pre + (int64_t)b * P.ldp;
@@ -324,10 +325,10 @@ __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     const float hb = aon ? P.head_b[la] : 0.f;
     const float* giz = P.gi_z + (int64_t)b * P.ldgi;
     const float* ghp = P.gh + (int64_t)b * P.ldgh;
-    const float2 gz_r = ld2(giz + i0, jn), gz_u = ld2(giz + D + i0, jn), gz_n = ld2(giz + 2 * D + i0, jn);
-    const float2 gh_r = ld2(ghp + i0, jn), gh_u = ld2(ghp + D + i0, jn), gh_n = ld2(ghp + 2 * D + i0, jn);
-    const float2 bi_r = ld2(P.b_ih + i0, jn), bi_u = ld2(P.b_ih + D + i0, jn), bi_n = ld2(P.b_ih + 2 * D + i0, jn);
-    const float2 hp = ld2(P.h_prev + (int64_t)b * P.ldh + i0, jn);
+    const float2 gz_r = ld2(giz + j0, jn), gz_u = ld2(giz + D + j0, jn), gz_n = ld2(giz + 2 * D + j0, jn);
+    const float2 gh_r = ld2(ghp + j0, jn), gh_u = ld2(ghp + D + j0, jn), gh_n = ld2(ghp + 2 * D + j0, jn);
+    const float2 bi_r = ld2(P.b_ih + j0, jn), bi_u = ld2(P.b_ih + D + j0, jn), bi_n = ld2(P.b_ih + 2 * D + j0, jn);
+    const float2 hp = ld2(P.h_prev + (int64_t)b * P.ldh + j0, jn);
     const int64_t forced = P.forced ? P.forced[(int64_t)b * P.ldf] : -1;
 #ifdef DRM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -374,13 +375,13 @@ __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     STAMP();
     // ---- GRU cell with the action's rows of gi_a
     const float* ga = P.gi_a + (int64_t)used * 3 * D;
-    const float2 ga_r = ld2(ga + i0, jn), ga_u = ld2(ga + D + i0, jn), ga_n = ld2(ga + 2 * D + i0, jn);
-    if (tid == 0) {
+    const float2 ga_r = ld2(ga + j0, jn), ga_u = ld2(ga + D + j0, jn), ga_n = ld2(ga + 2 * D + j0, jn);
+    if (tid == 0 && first) {
         P.a_used[(int64_t)b * P.ldau] = used;
         if (P.a_sampled) P.a_sampled[(int64_t)b * P.ldas] = ai;
     }
     const float ptot = group_sum<AMAX>(Pa);
-    if (P.logp_out && tid < P.A) P.logp_out[(int64_t)b * P.ldlp + tid] = logf(Pa) - logf(ptot);
+    if (P.logp_out && tid < P.A && first) P.logp_out[(int64_t)b * P.ldlp + tid] = logf(Pa) - logf(ptot);
     if (!jn) return;
     const float r0 = sigmoid_f(((gz_r.x + ga_r.x) + bi_r.x) + gh_r.x), r1 = sigmoid_f(((gz_r.y + ga_r.y) + bi_r.y) + gh_r.y);
     const float u0 = sigmoid_f(((gz_u.x + ga_u.x) + bi_u.x) + gh_u.x), u1 = sigmoid_f(((gz_u.y + ga_u.y) + bi_u.y) + gh_u.y);
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     float2 out;
     out.x = (1.0f - u0) * n0 + u0 * hp.x;
     out.y = (1.0f - u1) * n1 + u1 * hp.y;
-    *reinterpret_cast<float2*>(P.h_new + (int64_t)b * P.ldhn + i0) = out;
+    *reinterpret_cast<float2*>(P.h_new + (int64_t)b * P.ldhn + j0) = out;
     STAMP();
     STAMP_FLUSH(2000ull);
 }
@@ -708,6 +709,18 @@ static int cu_count() {
 int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t ldz, int latents, int classes,
                hipStream_t stream, int precision) {
     DRM_REQUIRE(np >= 1 && np <= 4 && M >= 1, DRM_EINVAL, "np=%d M=%d", np, M);
+    // few rows, plain problems: memory-bound; the K-looped few-row kernel cuts them into many more workgroups than
+    // 64-row tiles would (fp32, or bf16 weight images widened to fp32 in the kernel)
+    if (M <= SKINNY_MAX_ROWS && precision != 2 && std::getenv("DRM_NO_SKINNY_LOOP") == nullptr) {
+        bool ok = true;
+        for (int i = 0; i < np; ++i) ok = ok && specs[i].X && specs[i].W && specs[i].Y && skinny_loop_ok(specs[i]);
+        if (ok) {
+            const uint16_t* images[4] = {nullptr, nullptr, nullptr, nullptr};
+            bool have = precision == 1 && t_split != nullptr && t_split->planes == 1;
+            for (int i = 0; i < np && have; ++i) have = (images[i] = split_planes_of(specs[i], stream)) != nullptr;
+            return launch_skinny_loop(specs, np, M, stream, precision == 1, have ? images : nullptr);
+        }
+    }
     BigLaunch L{};
     int tiles = 0;
     double fl = 0, by = 0;
@@ -848,7 +861,7 @@ static WsLayout ws_layout(const drm_dims& d, int B, int H) {
         w.gi = take((size_t)B * 3 * d.D);
         w.logits = take((size_t)B * d.L * d.K);
     }
-    if (!wide && (B <= SKINNY_MAX_ROWS || B >= BIG_MIN_ROWS)) {
+    if ((!wide && (B <= SKINNY_MAX_ROWS || B >= BIG_MIN_ROWS)) || (wide && B <= SKINNY_MAX_ROWS && d.M <= 512)) {
         w.a1h = take((size_t)B * d.M);
         w.xz = take((size_t)B * d.D);
         if (B >= BIG_MIN_ROWS) {
@@ -1015,13 +1028,26 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
     // fp32 products at many rows take the same launch sequence with the large-row kernel in place of the few-row one:
     // LayerNorm + SiLU applied by the consumer while it loads (row statistics left behind by the producer)
     const bool fused = big && !wide && prec == 0 && std::getenv("DRM_NO_FUSED_STEP") == nullptr;
+    // few rows of a wide model (hidden width still within the register-resident kernel): the same launch sequence; the
+    // products over the recurrent width are memory-bound and run on the K-looped few-row kernel (bf16 weight images at
+    // precision 1), the LayerNorm'd ones over the hidden width on the register-resident one
+    const bool few_wide = B <= SKINNY_MAX_ROWS && wide && M <= 512 && prec != 2 && std::getenv("DRM_NO_FEW_WIDE") == nullptr;
     auto lin = [&](ProblemSpec* p, int np) -> int {
-        return few ? launch_skinny(p, np, B, s) : launch_big(p, np, B, nullptr, 0, 0, 0, s, 0);
+        if (few) return launch_skinny(p, np, B, s);
+        if (!few_wide) return launch_big(p, np, B, nullptr, 0, 0, 0, s, 0);
+        for (int i = 0; i < np;) {
+            const bool reg = p[i].K <= 512;
+            int j = i + 1;
+            while (j < np && (p[j].K <= 512) == reg) ++j;
+            if (int rc = reg ? launch_skinny(p + i, j - i, B, s) : launch_big(p + i, j - i, B, nullptr, 0, 0, 0, s, prec)) return rc;
+            i = j;
+        }
+        return DRM_OK;
     };
     float* st_a[2] = {fused ? ws + wl.st_a[0] : nullptr, fused ? ws + wl.st_a[1] : nullptr};
     float* st_d[2] = {fused ? ws + wl.st_d[0] : nullptr, fused ? ws + wl.st_d[1] : nullptr};
     int parts_a[2] = {0, 0}, parts_d[2] = {0, 0};
-    if (few || fused) {
+    if (few || fused || few_wide) {
         // ---- step-wise path.  Few rows: every layer is cut into ~256 workgroups; the draw of z and the one-hot
         // tables it selects (actor layer 1, GRU input) share one launch
         const int last_a = w->actor.n_layers - 1, last_d = w->dyn.n_layers - 1;
@@ -1100,8 +1126,9 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 a.logp_out = io->actor_logp_out ? io->actor_logp_out + (size_t)t * d.A : nullptr; a.ldlp = (int64_t)H * d.A;
                 ProfScope prof(PC_ACTOR_HEAD, s, 2.0 * B * M * d.A + 14.0 * B * D,
                                4.0 * ((double)B * M + (double)d.A * M + 2.0 * M + (double)B * D * 11.0 + 3.0 * D));
-                if (d.A <= 8) k_actor_gates<8><<<dim3(B), dim3(256), 0, s>>>(a);
-                else k_actor_gates<32><<<dim3(B), dim3(256), 0, s>>>(a);
+                const dim3 grid(B, (D + 511) / 512);
+                if (d.A <= 8) k_actor_gates<8><<<grid, dim3(256), 0, s>>>(a);
+                else k_actor_gates<32><<<grid, dim3(256), 0, s>>>(a);
                 DRM_LAUNCH_CHECK();
             }
             {

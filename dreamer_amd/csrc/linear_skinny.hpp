@@ -294,4 +294,128 @@ __global__ __launch_bounds__(256) void k_skinny_deep(const SkinnyLaunch L, const
     }
 }
 
+// ---- any K, few rows: wide models (recurrent width up to 4096) at the training / default batch -----------------
+// The same work split as k_skinny (wave = RW rows x CP columns, lane = 8 of every 512 k), walked over K in chunks of
+// 512 with the next chunk's loads in flight while the current one is multiplied; one wave-level reduction at the end.
+// A 16 x 4096 . 4096 x 12288 product is 200 MB of weights against 1.6 GFLOP: memory-bound, so the launch is cut into
+// N / CP workgroups (1536 at CP = 8) that each stream CP weight rows.  MODE 0: fp32 operands.  MODE 1 and 2: the bf16
+// form of the product (both operands rounded to bf16, fp32 accumulation) with the weights read as fp32 and rounded here
+// (1) or read from a bf16 image [N][K] (2: half the bytes).
+struct SkinnyLoopProblem {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const uint16_t* Wh;                        // bf16 image [N][K] or nullptr
+    const float* bias;
+    float* Y; int64_t ldy;
+    int N, K;
+    int wg_begin;
+};
+struct SkinnyLoopLaunch {
+    SkinnyLoopProblem p[SKINNY_MAX_PROBLEMS];
+    int np, M;
+};
+
+__device__ __forceinline__ f32x4 round_bf16x4(f32x4 v) {
+    return f32x4{(float)(__bf16)v.x, (float)(__bf16)v.y, (float)(__bf16)v.z, (float)(__bf16)v.w};
+}
+
+template <int RW, int CP, int MODE>
+__global__ __launch_bounds__(256) void k_skinny_loop(const SkinnyLoopLaunch L) {
+    constexpr int NV = RW * CP;
+    constexpr bool WH = MODE == 2;
+    static_assert(NV >= 2 && NV <= 64 && (NV & (NV - 1)) == 0, "RW*CP must be a power of two in [2, 64]");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int pi = L.np - 1;
+    while (pi > 0 && (int)blockIdx.x < L.p[pi].wg_begin) --pi;
+    const SkinnyLoopProblem& P = L.p[pi];
+    const int cg = blockIdx.x - P.wg_begin;
+    const int K = P.K;
+    const int row0 = blockIdx.y * (4 * RW) + wave * RW;
+    const float* xp[RW];
+    const float* wp[CP];
+    const uint16_t* hp[CP];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) xp[r] = P.X + (int64_t)min(row0 + r, L.M - 1) * P.ldx;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+        const int64_t n = min(cg * CP + c, P.N - 1);
+        wp[c] = P.W + n * P.ldw;
+        hp[c] = WH ? P.Wh + n * K : nullptr;
+    }
+    typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
+    f32x4 xa[2][RW], xb[2][RW], wa[2][CP], wb[2][CP];
+    u32x2k ha[2][CP], hb[2][CP];
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    // chunk c covers k = 512 c .. 512 c + 511; this lane's k: 4 lane .. + 3 and 256 + 4 lane .. + 3 of it (clamped, masked)
+#define SKL_LOAD(S, c)                                                                                 \
+    {                                                                                                  \
+        const int kA = (c) * 512 + 4 * lane, kB = kA + 256;                                            \
+        const int cA = min(kA, K - 4), cB = min(kB, K - 4);                                            \
+        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                               \
+            xa[S][r] = *reinterpret_cast<const f32x4*>(xp[r] + cA);                                    \
+            xb[S][r] = *reinterpret_cast<const f32x4*>(xp[r] + cB);                                    \
+        }                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < CP; ++q) {                                               \
+            if (WH) {                                                                                  \
+                ha[S][q] = *reinterpret_cast<const u32x2k*>(hp[q] + cA);                               \
+                hb[S][q] = *reinterpret_cast<const u32x2k*>(hp[q] + cB);                               \
+            } else {                                                                                   \
+                wa[S][q] = *reinterpret_cast<const f32x4*>(wp[q] + cA);                                \
+                wb[S][q] = *reinterpret_cast<const f32x4*>(wp[q] + cB);                                \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define SKL_WIDEN(h) f32x4{__builtin_bit_cast(float, (h).x << 16), __builtin_bit_cast(float, (h).x & 0xffff0000u), \
+                           __builtin_bit_cast(float, (h).y << 16), __builtin_bit_cast(float, (h).y & 0xffff0000u)}
+#define SKL_FMA(S, c)                                                                                  \
+    {                                                                                                  \
+        const int kA = (c) * 512 + 4 * lane, kB = kA + 256;                                            \
+        const bool vA = kA < K, vB = kB < K;                                                           \
+        _Pragma("unroll") for (int q = 0; q < CP; ++q) {                                               \
+            f32x4 a = WH ? SKL_WIDEN(ha[S][q]) : wa[S][q];                                             \
+            f32x4 b = WH ? SKL_WIDEN(hb[S][q]) : wb[S][q];                                             \
+            if (MODE == 1) { a = round_bf16x4(a); b = round_bf16x4(b); }                               \
+            if (!vA) a = zero;                                                                         \
+            if (!vB) b = zero;                                                                         \
+            _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                           \
+                float t = acc[r * CP + q];                                                             \
+                t = fmaf(xa[S][r].x, a.x, t); t = fmaf(xa[S][r].y, a.y, t);                            \
+                t = fmaf(xa[S][r].z, a.z, t); t = fmaf(xa[S][r].w, a.w, t);                            \
+                t = fmaf(xb[S][r].x, b.x, t); t = fmaf(xb[S][r].y, b.y, t);                            \
+                t = fmaf(xb[S][r].z, b.z, t); t = fmaf(xb[S][r].w, b.w, t);                            \
+                acc[r * CP + q] = t;                                                                   \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define SKL_ROUND_X(S)                                                                                 \
+    if (MODE != 0) {                                                                                   \
+        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                               \
+            xa[S][r] = round_bf16x4(xa[S][r]);                                                         \
+            xb[S][r] = round_bf16x4(xb[S][r]);                                                         \
+        }                                                                                              \
+    }
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    const int nc = (K + 511) / 512;
+    SKL_LOAD(0, 0)
+    for (int c = 0; c < nc; c += 2) {
+        SKL_LOAD(1, min(c + 1, nc - 1))
+        SKL_ROUND_X(0)
+        SKL_FMA(0, c)
+        SKL_LOAD(0, min(c + 2, nc - 1))
+        SKL_ROUND_X(1)
+        if (c + 1 < nc) SKL_FMA(1, c + 1)
+    }
+#undef SKL_ROUND_X
+#undef SKL_LOAD
+#undef SKL_WIDEN
+#undef SKL_FMA
+    const int idx = halving_index<NV>(lane);
+    const int m = row0 + idx / CP;
+    const int n = cg * CP + idx % CP;
+    const float tot = halving_sum64<NV>(acc, lane);
+    if (lane < NV && m < L.M && n < P.N) P.Y[(int64_t)m * P.ldy + n] = tot + (P.bias != nullptr ? P.bias[n] : 0.f);
+}
+
 }  // namespace drm

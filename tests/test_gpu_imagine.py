@@ -79,9 +79,11 @@ def test_teacher_forced_vs_oracle(B, H, A, layers):
     assert torch.equal(out["actions_sampled"].cpu()[clear_a], ref["actions"][clear_a])
 
 
-@pytest.mark.parametrize("B,H,D,M", [(6, 3, 1024, 768), (20, 2, 640, 1024), (260, 2, 1024, 544)])
+@pytest.mark.parametrize("B,H,D,M", [(6, 3, 1024, 768), (20, 2, 640, 1024), (260, 2, 1024, 544),
+                                     (16, 3, 4096, 512), (37, 2, 1056, 256), (3, 2, 2048, 64)])
 def test_wide_models_teacher_forced_vs_oracle(B, H, D, M):
-    """Widths beyond 512 (a scaled-up recurrent width) run on the large-row kernels for any batch."""
+    """Widths beyond 512 (a scaled-up recurrent width) run on the large-row kernels for any batch, or, at few rows with
+    a hidden width of at most 512, on the K-looped few-row kernel (the last three cases)."""
     d = dict(DIMS["small"], D=D, M=M, L=6, A=5)
     salt = 500 + B
     wm, actor, critic = build_models(d, salt)
@@ -94,10 +96,20 @@ def test_wide_models_teacher_forced_vs_oracle(B, H, D, M):
         ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
     ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
     out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea.to(DEV), "z": ez.to(DEV)},
-                  forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV), want_prior_logits=True)
+                  forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV), want_prior_logits=True,
+                  want_sampled=True)
     torch.cuda.synchronize()
     for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
         assert rel_err(out[key].cpu(), ref[key]) < TOL, key
+    # the draws agree with the oracle's wherever its top-two margin is clear of fp32 rounding
+    lp = O.log_unimix(ref["prior_logits"], 0.01) - ez.permute(1, 0, 2, 3).log()
+    top2 = lp.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert torch.equal(out["zidx_sampled"].cpu()[clear], ref_zidx[clear])
+    sc = (ref["actor_logp"].softmax(-1) / ea.permute(1, 0, 2)).log()
+    t2 = sc.topk(2, dim=-1).values
+    clear_a = (t2[..., 0] - t2[..., 1]) > 1e-4
+    assert torch.equal(out["actions_sampled"].cpu()[clear_a], ref["actions"][clear_a])
 
 
 def test_bf16_matrix_inputs_within_bf16_tolerance():
@@ -125,6 +137,33 @@ def test_bf16_matrix_inputs_within_bf16_tolerance():
         worst = max(worst, err)
         assert err < 1e-2, (key, err)
         assert rel_err(exact[key].cpu(), ref[key]) < TOL, key
+    assert worst > 1e-5   # the reduced-precision products really ran
+
+
+@pytest.mark.parametrize("B,H,D,M", [(16, 3, 4096, 512), (5, 2, 1056, 256)])
+def test_wide_model_few_rows_bf16_matrix_inputs(B, H, D, M):
+    """Few rows of a wide model with bf16 matrix inputs (the products over the recurrent width read bf16 weight images):
+    within the bf16 tolerance of the oracle, and not the fp32 result."""
+    d = dict(DIMS["small"], D=D, M=M, L=6, A=5)
+    salt = 700 + B
+    wm, actor, critic = build_models(d, salt)
+    ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    with torch.no_grad():
+        ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
+    ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
+    kw = dict(noise={"a": ea.to(DEV), "z": ez.to(DEV)}, forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV),
+              want_prior_logits=True)
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, precision="bf16", **kw)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+        err = rel_err(out[key].cpu(), ref[key])
+        worst = max(worst, err)
+        assert err < 1e-2, (key, err)
     assert worst > 1e-5   # the reduced-precision products really ran
 
 

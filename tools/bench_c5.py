@@ -42,12 +42,13 @@ def update():
     loss.backward()
 
 
-for prec in ("f32", "bf16"):
+ONLY = os.environ.get("C5_ONLY", "")          # "imagine16": just the few-row imagination block (for kernel traces)
+for prec in (() if ONLY else ("f32", "bf16")):
     wm.observe_precision = prec
     out[f"wm_loss_backward_ms_16x64_{prec}"] = timeit(update, 5)
     print(prec, "world-model loss + backward: %.2f ms" % out[f"wm_loss_backward_ms_16x64_{prec}"], flush=True)
 eng = ImagineEngine(wm, actor, critic)
-for Bi in (16, 1024):
+for Bi in ((16,) if ONLY == "imagine16" else (16, 1024)):
     h0 = torch.randn(Bi, D, generator=g).tanh().to(dev)
     z0 = torch.nn.functional.one_hot(torch.randint(0, K, (Bi, L), generator=g), K).float().to(dev)
     st = WorldModelState(h=h0, z=z0)
