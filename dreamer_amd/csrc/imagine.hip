@@ -971,7 +971,9 @@ extern "C" int drm_fused_linear_f32(const drm_linear_args* a, drm_stream_t strea
     DRM_REQUIRE(a->M >= 1, DRM_EINVAL, "M=%d", a->M);
     DRM_REQUIRE(!a->table || (a->classes >= 1 && a->latents >= 1), DRM_EINVAL, "bad gather shape");
     ProblemSpec s{a->X, a->ldx, a->ln_gamma, a->ln_beta, a->W, a->ldw, a->bias, a->table, a->ldt, a->Y, a->ldy, a->N, a->K};
-    if (a->M >= BIG_MIN_ROWS && a->ln_gamma == nullptr)
+    // many rows, or few rows over a long inner dimension (memory-bound: the K-looped few-row kernel)
+    const bool few_long = a->M <= SKINNY_MAX_ROWS && a->K > 512 && a->table == nullptr;
+    if ((a->M >= BIG_MIN_ROWS || few_long) && a->ln_gamma == nullptr)
         return launch_big(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream);
     return launch_store(&s, 1, a->M, a->zidx, a->ldz, a->latents, a->classes, (hipStream_t)stream);
 }

@@ -240,7 +240,7 @@ static inline int launch_skinny(const ProblemSpec* specs, int np, int M, hipStre
     return DRM_OK;
 }
 
-// any K, at most 64 rows, plain store epilogue (+ bias): the memory-bound products of wide models.  `images[i]`: a bf16
+// any K, at most 64 rows, plain store epilogue (+ bias): the memory-bound products of wide models (matrix-core kernel).  `images[i]`: a bf16
 // image [N][K] of problem i's weights, or nullptr (then every problem reads fp32 weights).  `bf16`: the bf16 form of the
 // product (operands rounded to bf16, fp32 accumulation).
 static inline bool skinny_loop_ok(const ProblemSpec& s) {
@@ -250,41 +250,36 @@ static inline bool skinny_loop_ok(const ProblemSpec& s) {
 static inline int launch_skinny_loop(const ProblemSpec* specs, int np, int M, hipStream_t stream, bool bf16, const uint16_t* const* images) {
     DRM_REQUIRE(np >= 1 && np <= SKINNY_MAX_PROBLEMS && M >= 1 && M <= SKINNY_MAX_ROWS, DRM_EINVAL, "np=%d M=%d", np, M);
     SkinnyLoopLaunch L{};
-    int ntot = 0;
-    bool wh = bf16 && images != nullptr;
     double fl = 0, by = 0;
+    bool wh = bf16 && images != nullptr;
     for (int i = 0; i < np; ++i) {
         DRM_REQUIRE(specs[i].X && specs[i].W && specs[i].Y && skinny_loop_ok(specs[i]), DRM_EINVAL, "problem %d does not fit the K-looped few-row kernel", i);
         wh = wh && images[i] != nullptr;
-        ntot += specs[i].N;
         const double n = specs[i].N, k = specs[i].K, m = M;
         fl += 2.0 * m * n * k;
         by += 4.0 * (m * k + n + m * n) + (images && images[i] ? 2.0 : 4.0) * n * k;
     }
-    const int rw = M <= 4 ? 1 : M <= 8 ? 2 : 4;
-    const int tiles_m = (M + 4 * rw - 1) / (4 * rw);
-    int cp = 2;
-    while (cp < 8 && (int64_t)tiles_m * ((ntot + cp - 1) / cp) > 1024) cp *= 2;
+    // 16 RT rows x 16 columns per workgroup
+    const int rt = M <= 16 ? 1 : M <= 32 ? 2 : 4;
+    for (int i = 0; i < np && wh; ++i) wh = specs[i].K % 8 == 0;
     int wgs = 0;
     for (int i = 0; i < np; ++i) {
         SkinnyLoopProblem& p = L.p[i];
         p.X = specs[i].X; p.ldx = specs[i].ldx; p.W = specs[i].W; p.ldw = specs[i].ldw; p.Wh = wh ? images[i] : nullptr;
         p.bias = specs[i].bias; p.Y = specs[i].Y; p.ldy = specs[i].ldy; p.N = specs[i].N; p.K = specs[i].K; p.wg_begin = wgs;
-        wgs += (specs[i].N + cp - 1) / cp;
+        wgs += (specs[i].N + 15) / 16;
     }
     L.np = np; L.M = M;
     ProfScope prof(PC_LINEAR, stream, fl, by);
-    const dim3 grid(wgs, tiles_m);
-#define DRM_SKL(RWV, CPV)                                                                   \
-    {                                                                                       \
-        if (wh) k_skinny_loop<RWV, CPV, 2><<<grid, dim3(256), 0, stream>>>(L);              \
-        else if (bf16) k_skinny_loop<RWV, CPV, 1><<<grid, dim3(256), 0, stream>>>(L);       \
-        else k_skinny_loop<RWV, CPV, 0><<<grid, dim3(256), 0, stream>>>(L);                 \
+    const dim3 grid(wgs);
+#define DRM_SKM(RTV)                                                                     \
+    {                                                                                    \
+        if (wh) k_skinny_mfma<RTV, 1, 2><<<grid, dim3(256), 0, stream>>>(L);             \
+        else if (bf16) k_skinny_mfma<RTV, 1, 1><<<grid, dim3(256), 0, stream>>>(L);      \
+        else k_skinny_mfma<RTV, 1, 0><<<grid, dim3(256), 0, stream>>>(L);                \
     }
-#define DRM_SKL_CP(RWV) { if (cp == 8) DRM_SKL(RWV, 8) else if (cp == 4) DRM_SKL(RWV, 4) else DRM_SKL(RWV, 2) }
-    if (rw == 1) DRM_SKL_CP(1) else if (rw == 2) DRM_SKL_CP(2) else DRM_SKL_CP(4)
-#undef DRM_SKL_CP
-#undef DRM_SKL
+    if (rt == 1) DRM_SKM(1) else if (rt == 2) DRM_SKM(2) else DRM_SKM(4)
+#undef DRM_SKM
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

@@ -295,12 +295,9 @@ __global__ __launch_bounds__(256) void k_skinny_deep(const SkinnyLaunch L, const
 }
 
 // ---- any K, few rows: wide models (recurrent width up to 4096) at the training / default batch -----------------
-// The same work split as k_skinny (wave = RW rows x CP columns, lane = 8 of every 512 k), walked over K in chunks of
-// 512 with the next chunk's loads in flight while the current one is multiplied; one wave-level reduction at the end.
-// A 16 x 4096 . 4096 x 12288 product is 200 MB of weights against 1.6 GFLOP: memory-bound, so the launch is cut into
-// N / CP workgroups (1536 at CP = 8) that each stream CP weight rows.  MODE 0: fp32 operands.  MODE 1 and 2: the bf16
-// form of the product (both operands rounded to bf16, fp32 accumulation) with the weights read as fp32 and rounded here
-// (1) or read from a bf16 image [N][K] (2: half the bytes).
+// A 16 x 4096 . 4096 x 12288 product is 200 MB of weights against 1.6 GFLOP: memory-bound; the launch is cut into
+// N / 16 workgroups that each stream 16 weight rows.  Weights come as fp32, or (bf16 form of the product: both operands
+// rounded to bf16, fp32 accumulation) as fp32 rounded in the kernel, or from a bf16 image [N][K] (half the bytes).
 struct SkinnyLoopProblem {
     const float* X; int64_t ldx;
     const float* W; int64_t ldw;
@@ -319,103 +316,159 @@ __device__ __forceinline__ f32x4 round_bf16x4(f32x4 v) {
     return f32x4{(float)(__bf16)v.x, (float)(__bf16)v.y, (float)(__bf16)v.z, (float)(__bf16)v.w};
 }
 
-template <int RW, int CP, int MODE>
-__global__ __launch_bounds__(256) void k_skinny_loop(const SkinnyLoopLaunch L) {
-    constexpr int NV = RW * CP;
-    constexpr bool WH = MODE == 2;
-    static_assert(NV >= 2 && NV <= 64 && (NV & (NV - 1)) == 0, "RW*CP must be a power of two in [2, 64]");
+// Matrix-core kernel.  Workgroup = 16 CT output columns x 16 RT rows; its four waves split K in
+// interleaved blocks and add their partial tiles through LDS at the end.  Each wave moves its blocks of W and X
+// through an LDS area of its own: the global loads are laid out for the memory system (a quarter-wave reads 256
+// contiguous bytes of one row), the MFMA fragments (16 rows x 4 k-groups per register) are then read back from LDS with
+// ds_read_b128; no workgroup barrier inside the K loop.  A weight element is requested from the vector cache once.
+// The 16x16 tile of v_mfma_f32_16x16x4_f32 holds the default batch of 16 rows exactly.
+//   MODE 0 / 1: fp32 MFMA (1: operands rounded to bf16 first); blocks of 64 k; lane (c = lane & 15, g = lane >> 4) takes
+//               k = 16 j + 4 g .. + 3 for j = 0..3: MFMA number 4 j + e multiplies the lanes' element e.
+//   MODE 2:     v_mfma_f32_16x16x32_bf16 on a bf16 weight image, X rounded to bf16 on its way into LDS; blocks of 128 k;
+//               the lane takes k = 32 j + 8 g .. + 7.
+// An LDS row is 256 bytes of payload + 16: the 16 lanes that a ds_read_b128 serves together start 4 banks apart per
+// row and cover all 64 banks once.
+typedef __bf16 skm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 skm_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int skm_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int skm_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // orders this wave's LDS writes before its later LDS reads by other lanes (LDS operations of one wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int RT, int CT, int MODE>
+__global__ __launch_bounds__(256) void k_skinny_mfma(const SkinnyLoopLaunch L) {
+    constexpr int NT = RT * CT;
+    static_assert(NT <= 4 && CT <= 2, "tile shapes: (1,1) (1,2) (2,1) (2,2) (4,1)");
+    constexpr int KB = MODE == 2 ? 128 : 64;          // k per block
+    constexpr int KW = MODE == 2 ? 8 : 4;             // k per 16-byte piece of a weight row
+    constexpr int LDR = 68;                           // dwords per LDS row
+    constexpr int NWL = CT * 4;                       // weight loads per lane and block (4 rows per instruction)
+    constexpr int NXL = MODE == 2 ? RT * 8 : RT * 4;  // X loads (MODE 2: 2 rows of 128 fp32 per instruction)
+    constexpr int WAVE_DW = (CT + RT) * 16 * LDR;
+    static_assert(4 * WAVE_DW >= 4 * NT * 4 * 64, "the partial tiles fit the staging area");
+    __shared__ __attribute__((aligned(16))) float smem[4 * WAVE_DW];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, kg = lane >> 4;
+    float* sw = smem + wave * WAVE_DW;
+    float* sx = sw + CT * 16 * LDR;
     int pi = L.np - 1;
     while (pi > 0 && (int)blockIdx.x < L.p[pi].wg_begin) --pi;
     const SkinnyLoopProblem& P = L.p[pi];
-    const int cg = blockIdx.x - P.wg_begin;
+    const int n0 = ((int)blockIdx.x - P.wg_begin) * (16 * CT);
     const int K = P.K;
-    const int row0 = blockIdx.y * (4 * RW) + wave * RW;
-    const float* xp[RW];
-    const float* wp[CP];
-    const uint16_t* hp[CP];
+    // loads: lane = (row within the instruction, 16-byte piece of the row's block)
+    const float* wrow[NWL];
+    const uint16_t* hrow[NWL];
+    const float* xrow[NXL];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) xp[r] = P.X + (int64_t)min(row0 + r, L.M - 1) * P.ldx;
-#pragma unroll
-    for (int c = 0; c < CP; ++c) {
-        const int64_t n = min(cg * CP + c, P.N - 1);
-        wp[c] = P.W + n * P.ldw;
-        hp[c] = WH ? P.Wh + n * K : nullptr;
+    for (int i = 0; i < NWL; ++i) {
+        const int64_t n = min(n0 + 4 * i + (lane >> 4), P.N - 1);
+        wrow[i] = P.W + n * P.ldw;
+        hrow[i] = MODE == 2 ? P.Wh + n * K : nullptr;
     }
-    typedef unsigned int u32x2k __attribute__((ext_vector_type(2)));
-    f32x4 xa[2][RW], xb[2][RW], wa[2][CP], wb[2][CP];
-    u32x2k ha[2][CP], hb[2][CP];
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    // chunk c covers k = 512 c .. 512 c + 511; this lane's k: 4 lane .. + 3 and 256 + 4 lane .. + 3 of it (clamped, masked)
-#define SKL_LOAD(S, c)                                                                                 \
+    const int xq = MODE == 2 ? (lane & 31) : (lane & 15);            // 4-float piece of an X row's block
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+        const int m = MODE == 2 ? 2 * i + (lane >> 5) : 4 * i + (lane >> 4);
+        xrow[i] = P.X + (int64_t)min(m, L.M - 1) * P.ldx;
+    }
+    f32x4 wv[2][NWL], xv[2][NXL];
+    skm_u32x4 hv[2][NWL];
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nblk = (K + KB - 1) / KB, last = nblk - 1;
+#define SKM_LOAD(S, blk)                                                                               \
     {                                                                                                  \
-        const int kA = (c) * 512 + 4 * lane, kB = kA + 256;                                            \
-        const int cA = min(kA, K - 4), cB = min(kB, K - 4);                                            \
-        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                               \
-            xa[S][r] = *reinterpret_cast<const f32x4*>(xp[r] + cA);                                    \
-            xb[S][r] = *reinterpret_cast<const f32x4*>(xp[r] + cB);                                    \
+        const int kb = min((blk), last) * KB;                                                          \
+        const int ckw = min(kb + KW * (lane & 15), K - KW), ckx = min(kb + 4 * xq, K - 4);             \
+        _Pragma("unroll") for (int i = 0; i < NWL; ++i) {                                              \
+            if (MODE == 2) hv[S][i] = *reinterpret_cast<const skm_u32x4*>(hrow[i] + ckw);              \
+            else wv[S][i] = *reinterpret_cast<const f32x4*>(wrow[i] + ckw);                            \
         }                                                                                              \
-        _Pragma("unroll") for (int q = 0; q < CP; ++q) {                                               \
-            if (WH) {                                                                                  \
-                ha[S][q] = *reinterpret_cast<const u32x2k*>(hp[q] + cA);                               \
-                hb[S][q] = *reinterpret_cast<const u32x2k*>(hp[q] + cB);                               \
+        _Pragma("unroll") for (int i = 0; i < NXL; ++i) xv[S][i] = *reinterpret_cast<const f32x4*>(xrow[i] + ckx); \
+    }
+    // registers -> LDS; weights beyond K (or of a block past the end) become zeros, so what X holds there does not count
+#define SKM_STAGE(S, blk)                                                                              \
+    {                                                                                                  \
+        const bool valid = (blk) < nblk && (blk) * KB + KW * (lane & 15) < K;                          \
+        _Pragma("unroll") for (int i = 0; i < NWL; ++i) {                                              \
+            float* dst = sw + (4 * i + (lane >> 4)) * LDR + 4 * (lane & 15);                           \
+            if (MODE == 2) {                                                                           \
+                *reinterpret_cast<skm_u32x4*>(dst) = valid ? hv[S][i] : skm_u32x4{0u, 0u, 0u, 0u};     \
             } else {                                                                                   \
-                wa[S][q] = *reinterpret_cast<const f32x4*>(wp[q] + cA);                                \
-                wb[S][q] = *reinterpret_cast<const f32x4*>(wp[q] + cB);                                \
+                const f32x4 v = MODE == 1 ? round_bf16x4(wv[S][i]) : wv[S][i];                         \
+                *reinterpret_cast<f32x4*>(dst) = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};                \
+            }                                                                                          \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NXL; ++i) {                                              \
+            const f32x4 v = xv[S][i];                                                                  \
+            if (MODE == 2) {                                                                           \
+                const skm_bf16x4 h = skm_bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};   \
+                *reinterpret_cast<skm_u32x2*>(sx + (2 * i + (lane >> 5)) * LDR + 2 * (lane & 31)) = __builtin_bit_cast(skm_u32x2, h); \
+            } else {                                                                                   \
+                *reinterpret_cast<f32x4*>(sx + (4 * i + (lane >> 4)) * LDR + 4 * (lane & 15)) = MODE == 1 ? round_bf16x4(v) : v; \
             }                                                                                          \
         }                                                                                              \
     }
-#define SKL_WIDEN(h) f32x4{__builtin_bit_cast(float, (h).x << 16), __builtin_bit_cast(float, (h).x & 0xffff0000u), \
-                           __builtin_bit_cast(float, (h).y << 16), __builtin_bit_cast(float, (h).y & 0xffff0000u)}
-#define SKL_FMA(S, c)                                                                                  \
-    {                                                                                                  \
-        const int kA = (c) * 512 + 4 * lane, kB = kA + 256;                                            \
-        const bool vA = kA < K, vB = kB < K;                                                           \
-        _Pragma("unroll") for (int q = 0; q < CP; ++q) {                                               \
-            f32x4 a = WH ? SKL_WIDEN(ha[S][q]) : wa[S][q];                                             \
-            f32x4 b = WH ? SKL_WIDEN(hb[S][q]) : wb[S][q];                                             \
-            if (MODE == 1) { a = round_bf16x4(a); b = round_bf16x4(b); }                               \
-            if (!vA) a = zero;                                                                         \
-            if (!vB) b = zero;                                                                         \
-            _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                           \
-                float t = acc[r * CP + q];                                                             \
-                t = fmaf(xa[S][r].x, a.x, t); t = fmaf(xa[S][r].y, a.y, t);                            \
-                t = fmaf(xa[S][r].z, a.z, t); t = fmaf(xa[S][r].w, a.w, t);                            \
-                t = fmaf(xb[S][r].x, b.x, t); t = fmaf(xb[S][r].y, b.y, t);                            \
-                t = fmaf(xb[S][r].z, b.z, t); t = fmaf(xb[S][r].w, b.w, t);                            \
-                acc[r * CP + q] = t;                                                                   \
-            }                                                                                          \
+#define SKM_MMA()                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                    \
+        f32x4 bw[CT], ax[RT];                                                                          \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c) bw[c] = *reinterpret_cast<const f32x4*>(sw + (16 * c + lr) * LDR + 16 * j + 4 * kg); \
+        _Pragma("unroll") for (int r = 0; r < RT; ++r) ax[r] = *reinterpret_cast<const f32x4*>(sx + (16 * r + lr) * LDR + 16 * j + 4 * kg); \
+        if (MODE == 2) {                                                                               \
+            _Pragma("unroll") for (int r = 0; r < RT; ++r)                                             \
+                _Pragma("unroll") for (int c = 0; c < CT; ++c)                                         \
+                    acc[r * CT + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(skm_bf16x8, ax[r]), \
+                                          __builtin_bit_cast(skm_bf16x8, bw[c]), acc[r * CT + c], 0, 0, 0); \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+                _Pragma("unroll") for (int r = 0; r < RT; ++r)                                         \
+                    _Pragma("unroll") for (int c = 0; c < CT; ++c)                                     \
+                        acc[r * CT + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[r][e], bw[c][e], acc[r * CT + c], 0, 0, 0); \
         }                                                                                              \
     }
-#define SKL_ROUND_X(S)                                                                                 \
-    if (MODE != 0) {                                                                                   \
-        _Pragma("unroll") for (int r = 0; r < RW; ++r) {                                               \
-            xa[S][r] = round_bf16x4(xa[S][r]);                                                         \
-            xb[S][r] = round_bf16x4(xb[S][r]);                                                         \
-        }                                                                                              \
+    // this wave's blocks: wave, wave + 4, ...; two blocks of loads in flight while a third is multiplied
+    SKM_LOAD(0, wave)
+    SKM_LOAD(1, wave + 4)
+    for (int b = wave; b < nblk; b += 8) {
+        SKM_STAGE(0, b)
+        wave_lds_sync();
+        SKM_LOAD(0, b + 8)
+        SKM_MMA()
+        wave_lds_sync();
+        SKM_STAGE(1, b + 4)
+        wave_lds_sync();
+        SKM_LOAD(1, b + 12)
+        SKM_MMA()
+        wave_lds_sync();
     }
-    float acc[NV];
+#undef SKM_LOAD
+#undef SKM_STAGE
+#undef SKM_MMA
+    __syncthreads();
+    float (*red)[NT * 4][64] = reinterpret_cast<float (*)[NT * 4][64]>(smem);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-    const int nc = (K + 511) / 512;
-    SKL_LOAD(0, 0)
-    for (int c = 0; c < nc; c += 2) {
-        SKL_LOAD(1, min(c + 1, nc - 1))
-        SKL_ROUND_X(0)
-        SKL_FMA(0, c)
-        SKL_LOAD(0, min(c + 2, nc - 1))
-        SKL_ROUND_X(1)
-        if (c + 1 < nc) SKL_FMA(1, c + 1)
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t * 4 + r][lane] = acc[t][r];
+    __syncthreads();
+    // accumulator element r of lane l of tile (rt, ct): row 16 rt + 4 (l >> 4) + r, column 16 ct + (l & 15)
+#pragma unroll
+    for (int v = 0; v < NT; ++v) {
+        const int idx = v * 256 + tid;
+        const int e = idx >> 6, l = idx & 63;
+        const int t = e >> 2, r = e & 3;
+        const int m = (t / CT) * 16 + 4 * (l >> 4) + r;
+        const int n = n0 + (t % CT) * 16 + (l & 15);
+        const float tot = (red[0][e][l] + red[1][e][l]) + (red[2][e][l] + red[3][e][l]);
+        if (m < L.M && n < P.N) P.Y[(int64_t)m * P.ldy + n] = tot + (P.bias != nullptr ? P.bias[n] : 0.f);
     }
-#undef SKL_ROUND_X
-#undef SKL_LOAD
-#undef SKL_WIDEN
-#undef SKL_FMA
-    const int idx = halving_index<NV>(lane);
-    const int m = row0 + idx / CP;
-    const int n = cg * CP + idx % CP;
-    const float tot = halving_sum64<NV>(acc, lane);
-    if (lane < NV && m < L.M && n < P.N) P.Y[(int64_t)m * P.ldy + n] = tot + (P.bias != nullptr ? P.bias[n] : 0.f);
 }
 
 }  // namespace drm
