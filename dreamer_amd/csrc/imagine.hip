@@ -658,6 +658,92 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// out[r, n] += sum_l tab[(l*32 + z[r, l]), n] for many rows (the heads over all B*H imagined states): the one-hot part of
+// a first layer over cat[h, z] (lib/world_model.py:215-216, 259-260, lib/critic.py value path).  Gathering the 32 table
+// rows per output row from L2 costs more than the product over h itself; here a workgroup owns a slab of 32 columns of
+// one table, copies it into LDS once (L*32 rows x 128 bytes <= 128 KB) and walks its share of the rows, so the gather
+// runs at LDS speed and global memory sees one read-modify-write of the output.  Optionally leaves the row statistics
+// (sum, sum of squares over the slab's columns: one part per slab) for a consumer that normalises while loading.
+// ------------------------------------------------------------------------------------------------
+struct TableAddJob { const float* tab; int64_t ldt; float* out; int64_t ldo; float* stats; int N; };
+struct TableAddArgs {
+    TableAddJob j[3];
+    int nj, slabs;                      // slabs per job = N / 32 (the same for every job)
+    const uint8_t* zidx; int64_t ldz;   // (rows, L) class indices
+    int rows, L;
+};
+constexpr int TABLE_ADD_MAX_L = 32;
+
+__global__ __launch_bounds__(1024) void k_table_add(const TableAddArgs P) {
+    __shared__ __attribute__((aligned(16))) float s_tab[TABLE_ADD_MAX_L * 32 * 32];
+    const int tid = threadIdx.x;
+    const int job = blockIdx.x / P.slabs, slab = blockIdx.x - job * P.slabs;
+    const TableAddJob& J = P.j[job];
+    const int n0 = slab * 32;
+    const int c4 = (tid & 7) * 4;
+    for (int r = tid >> 3; r < P.L * 32; r += 128)
+        *reinterpret_cast<float4*>(&s_tab[r * 32 + c4]) = *reinterpret_cast<const float4*>(J.tab + (int64_t)r * J.ldt + n0 + c4);
+    __syncthreads();
+    // rows of this workgroup: a contiguous share; 128 rows per pass, 8 threads per row
+    const int per = (P.rows + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(r0 + per, P.rows);
+    const int nw = (P.L + 3) >> 2;      // index words per row
+    auto load_z = [&](int r, uint32_t (&zw)[8]) {
+        const uint8_t* zp = P.zidx + (int64_t)r * P.ldz;
+        if (((reinterpret_cast<uintptr_t>(zp) | (uintptr_t)P.L) & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zw[i] = i < nw ? reinterpret_cast<const uint32_t*>(zp)[i] : 0u;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) w |= (4 * i + b < P.L ? (uint32_t)zp[4 * i + b] : 0u) << (8 * b);
+                zw[i] = w;
+            }
+        }
+    };
+    int r = r0 + (tid >> 3);
+    uint32_t zw[8], zn[8];
+    float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
+    if (r < r1) {
+        load_z(r, zw);
+        cur = *reinterpret_cast<const float4*>(J.out + (int64_t)r * J.ldo + n0 + c4);
+    }
+    for (; r < r1; r += 128) {
+        const int rn = r + 128;
+        if (rn < r1) {                  // the next pass's operands travel while this pass reads LDS
+            load_z(rn, zn);
+            nxt = *reinterpret_cast<const float4*>(J.out + (int64_t)rn * J.ldo + n0 + c4);
+        }
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int l = 4 * i + b;
+                if (l < P.L) {
+                    const int k = (zw[i] >> (8 * b)) & 31;
+                    const float4 u = *reinterpret_cast<const float4*>(&s_tab[(l * 32 + k) * 32 + c4]);
+                    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                }
+            }
+        }
+        const float4 y = make_float4(cur.x + a.x, cur.y + a.y, cur.z + a.z, cur.w + a.w);
+        *reinterpret_cast<float4*>(J.out + (int64_t)r * J.ldo + n0 + c4) = y;
+        if (J.stats != nullptr) {       // uniform per workgroup
+            const float sm = group_sum<8>((y.x + y.y) + (y.z + y.w));
+            const float sq = group_sum<8>(fmaf(y.x, y.x, y.y * y.y) + fmaf(y.z, y.z, y.w * y.w));
+            if ((tid & 7) == 0)
+                *reinterpret_cast<float2*>(J.stats + ((int64_t)r * P.slabs + slab) * 2) = make_float2(sm, sq);
+        }
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zw[i] = zn[i];
+    }
+}
+
 // bf16 images of the weight operands of one call (precision 2: three planes, the exact split; precision 1: one plane,
 // the rounded weights): made on first use inside the call, found again by (pointer, shape) afterwards.  The area lives
 // in the caller's workspace.
@@ -1274,6 +1360,8 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
     float* st_h[3][2];
     int parts_h[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) st_h[i][j] = fused ? ws + wl.st_h[i][j] : nullptr;
+    // many rows of a default-width model: the one-hot part of the first layers is added by a kernel of its own
+    const bool table_add = big && !wide && L <= TABLE_ADD_MAX_L && rows >= BIG_MIN_ROWS && std::getenv("DRM_NO_TABLE_ADD") == nullptr;
     for (int dep = 0; dep <= depth_max; ++dep) {
         ProblemSpec p[3];
         int who[3];
@@ -1283,7 +1371,8 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
             // a later matrix product normalises this output while loading it (the scalar finish kernel normalises by itself)
             const bool feeds_product = dep + 1 < m.n_layers || (i == 2 && dep + 1 == m.n_layers);
             if (dep == 0) {
-                p[np] = ProblemSpec{io->h_out, D, nullptr, nullptr, m.w[0], S, m.b[0], pack + tabs[i], M, ws + wl.head[i][0], M, M, D};
+                p[np] = ProblemSpec{io->h_out, D, nullptr, nullptr, m.w[0], S, m.b[0], table_add ? nullptr : pack + tabs[i], M,
+                                    ws + wl.head[i][0], M, M, D};
             } else if (dep < m.n_layers) {
                 p[np] = ProblemSpec{ws + wl.head[i][(dep - 1) & 1], M, m.ln_g[dep - 1], m.ln_b[dep - 1], m.w[dep], M, m.b[dep],
                                     nullptr, 0, ws + wl.head[i][dep & 1], M, M, M};
@@ -1294,7 +1383,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 continue;
             }
             if (dep > 0) { p[np].stats_in = st_h[i][(dep - 1) & 1]; p[np].parts_in = parts_h[i][(dep - 1) & 1]; }
-            if (dep < m.n_layers && feeds_product) p[np].stats_out = st_h[i][dep & 1];
+            if (dep < m.n_layers && feeds_product && !(dep == 0 && table_add)) p[np].stats_out = st_h[i][dep & 1];
             who[np++] = i;
         }
         if (np == 0) continue;
@@ -1305,6 +1394,23 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
         } else {
             for (int q = 0; q < np; ++q) { p[q].stats_in = nullptr; p[q].parts_in = 0; p[q].stats_out = nullptr; }
             if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s, prec)) return rc;
+        }
+        if (dep == 0 && table_add) {
+            // the z part of the first layers: one pass over the three outputs with the tables' column slabs held in LDS
+            TableAddArgs a{};
+            a.nj = np; a.slabs = M / 32; a.zidx = io->zidx_out; a.ldz = L; a.rows = rows; a.L = L;
+            for (int q = 0; q < np; ++q) {
+                const int i = who[q];
+                const bool want_stats = fused && (1 < heads[i]->n_layers || i == 2);
+                a.j[q] = TableAddJob{pack + tabs[i], M, ws + wl.head[i][0], M, want_stats ? st_h[i][0] : nullptr, M};
+                if (want_stats) parts_h[i][0] = a.slabs;
+            }
+            const int slabs = np * a.slabs;
+            int split = (cu_count() + slabs - 1) / slabs;
+            if (split > (rows + 127) / 128) split = (rows + 127) / 128;
+            ProfScope prof(PC_SAMPLE, s, (double)rows * L * M * np, 4.0 * np * (2.0 * rows * M + (double)L * 32 * M) + (double)rows * L);
+            k_table_add<<<dim3(slabs, split), dim3(1024), 0, s>>>(a);
+            DRM_LAUNCH_CHECK();
         }
     }
     {
