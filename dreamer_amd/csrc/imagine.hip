@@ -659,17 +659,24 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
 }
 
 // ------------------------------------------------------------------------------------------------
-// out[r, n] += sum_l tab[(l*32 + z[r, l]), n] for many rows (the heads over all B*H imagined states): the one-hot part of
-// a first layer over cat[h, z] (lib/world_model.py:215-216, 259-260, lib/critic.py value path).  Gathering the 32 table
+// out[r, n] = base[r, n] + sum_l tab[(l*32 + z[r, l]), n] for many rows: the one-hot part of a first layer over
+// cat[h, z] (heads over all B*H imagined states: lib/world_model.py:215-216, 259-260, lib/critic.py value path; per
+// step: the actor's first layer and the GRU input row, lib/actor.py:94-99, lib/world_model.py:64-70).  Gathering the 32 table
 // rows per output row from L2 costs more than the product over h itself; here a workgroup owns a slab of 32 columns of
 // one table, copies it into LDS once (L*32 rows x 128 bytes <= 128 KB) and walks its share of the rows, so the gather
 // runs at LDS speed and global memory sees one read-modify-write of the output.  Optionally leaves the row statistics
 // (sum, sum of squares over the slab's columns: one part per slab) for a consumer that normalises while loading.
 // ------------------------------------------------------------------------------------------------
-struct TableAddJob { const float* tab; int64_t ldt; float* out; int64_t ldo; float* stats; int N; };
+struct TableAddJob {
+    const float* tab; int64_t ldt;
+    const float* base; int64_t ldb;     // out = base + sum (base may be out itself; ldb = 0: one vector for every row)
+    float* out; int64_t ldo;
+    float* stats;                       // or nullptr
+    int N, slab_begin;                  // columns (multiple of 32), first blockIdx.x of this job
+};
 struct TableAddArgs {
     TableAddJob j[3];
-    int nj, slabs;                      // slabs per job = N / 32 (the same for every job)
+    int nj;
     const uint8_t* zidx; int64_t ldz;   // (rows, L) class indices
     int rows, L;
 };
@@ -678,8 +685,10 @@ constexpr int TABLE_ADD_MAX_L = 32;
 __global__ __launch_bounds__(1024) void k_table_add(const TableAddArgs P) {
     __shared__ __attribute__((aligned(16))) float s_tab[TABLE_ADD_MAX_L * 32 * 32];
     const int tid = threadIdx.x;
-    const int job = blockIdx.x / P.slabs, slab = blockIdx.x - job * P.slabs;
+    int job = P.nj - 1;
+    while (job > 0 && (int)blockIdx.x < P.j[job].slab_begin) --job;
     const TableAddJob& J = P.j[job];
+    const int slab = blockIdx.x - J.slab_begin, parts = J.N >> 5;
     const int n0 = slab * 32;
     const int c4 = (tid & 7) * 4;
     for (int r = tid >> 3; r < P.L * 32; r += 128)
@@ -709,13 +718,13 @@ __global__ __launch_bounds__(1024) void k_table_add(const TableAddArgs P) {
     float4 cur = make_float4(0.f, 0.f, 0.f, 0.f), nxt = cur;
     if (r < r1) {
         load_z(r, zw);
-        cur = *reinterpret_cast<const float4*>(J.out + (int64_t)r * J.ldo + n0 + c4);
+        cur = *reinterpret_cast<const float4*>(J.base + (int64_t)r * J.ldb + n0 + c4);
     }
     for (; r < r1; r += 128) {
         const int rn = r + 128;
         if (rn < r1) {                  // the next pass's operands travel while this pass reads LDS
             load_z(rn, zn);
-            nxt = *reinterpret_cast<const float4*>(J.out + (int64_t)rn * J.ldo + n0 + c4);
+            nxt = *reinterpret_cast<const float4*>(J.base + (int64_t)rn * J.ldb + n0 + c4);
         }
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(1024) void k_table_add(const TableAddArgs P) {
             const float sm = group_sum<8>((y.x + y.y) + (y.z + y.w));
             const float sq = group_sum<8>(fmaf(y.x, y.x, y.y * y.y) + fmaf(y.z, y.z, y.w * y.w));
             if ((tid & 7) == 0)
-                *reinterpret_cast<float2*>(J.stats + ((int64_t)r * P.slabs + slab) * 2) = make_float2(sm, sq);
+                *reinterpret_cast<float2*>(J.stats + ((int64_t)r * parts + slab) * 2) = make_float2(sm, sq);
         }
         cur = nxt;
 #pragma unroll
@@ -1139,7 +1148,41 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
         // ---- step-wise path.  Few rows: every layer is cut into ~256 workgroups; the draw of z and the one-hot
         // tables it selects (actor layer 1, GRU input) share one launch
         const int last_a = w->actor.n_layers - 1, last_d = w->dyn.n_layers - 1;
+        // many rows: the draw and the table rows are two launches, the tables' column slabs held in LDS by the second
+        const bool step_table_add = fused && L <= TABLE_ADD_MAX_L && std::getenv("DRM_NO_TABLE_ADD") == nullptr;
         auto sample_gather = [&](int t, bool draw, bool gather) -> int {
+            if (step_table_add) {
+                if (draw) {
+                    SampleRowsArgs a{};
+                    a.logits = ws + wl.logits; a.ldlg = LK; a.expo = io->expo_z + (size_t)t * nb * LK; a.lde = LK;
+                    a.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.ldf = (int64_t)H * L;
+                    a.idx_used = io->zidx_out + (size_t)t * L; a.ldu = (int64_t)H * L;
+                    a.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.ldsm = (int64_t)H * L;
+                    a.z_dense = io->z_out ? io->z_out + (size_t)t * LK : nullptr; a.ldzd = (int64_t)H * LK;
+                    a.logits_out = io->prior_logits_out ? io->prior_logits_out + (size_t)t * LK : nullptr; a.ldlo = (int64_t)H * LK;
+                    a.B = B; a.L = L; a.log1m_eps = l1m; a.log_eps_over_k = lek;
+                    a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
+                    const int64_t blocks = ((int64_t)B * L + 31) / 32;
+                    ProfScope prof(PC_SAMPLE, s, 12.0 * B * LK, (double)B * L * (256.0 + (a.z_dense ? 128.0 : 0.0) + 1.0));
+                    k_sample_rows<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s>>>(a);
+                    DRM_LAUNCH_CHECK();
+                }
+                if (gather) {
+                    TableAddArgs a{};
+                    a.nj = 2; a.rows = B; a.L = L;
+                    a.zidx = draw ? io->zidx_out + (size_t)t * L : io->zidx0; a.ldz = draw ? (int64_t)H * L : L;
+                    a.j[0] = TableAddJob{pack + pl.actor_zT, M, ws + wl.a1h, M, ws + wl.a_pre[0], M, st_a[0], M, 0};
+                    a.j[1] = TableAddJob{pack + pl.lin_zT, D, w->lin_b, 0, ws + wl.xz, D, nullptr, D, M / 32};
+                    parts_a[0] = M / 32;
+                    const int slabs = M / 32 + D / 32;
+                    int split = (cu_count() + slabs - 1) / slabs;
+                    if (split > (B + 127) / 128) split = (B + 127) / 128;
+                    ProfScope prof(PC_SAMPLE, s, (double)B * L * (M + D), 4.0 * ((double)B * (3.0 * M + D) + (double)L * 32 * (M + D)) + (double)B * L);
+                    k_table_add<<<dim3(slabs, split), dim3(1024), 0, s>>>(a);
+                    DRM_LAUNCH_CHECK();
+                }
+                return DRM_OK;
+            }
             SampleGatherArgs a{};
             a.s.B = B; a.s.L = L; a.s.log1m_eps = l1m; a.s.log_eps_over_k = lek;
             a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
@@ -1398,14 +1441,15 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
         if (dep == 0 && table_add) {
             // the z part of the first layers: one pass over the three outputs with the tables' column slabs held in LDS
             TableAddArgs a{};
-            a.nj = np; a.slabs = M / 32; a.zidx = io->zidx_out; a.ldz = L; a.rows = rows; a.L = L;
+            a.nj = np; a.zidx = io->zidx_out; a.ldz = L; a.rows = rows; a.L = L;
             for (int q = 0; q < np; ++q) {
                 const int i = who[q];
                 const bool want_stats = fused && (1 < heads[i]->n_layers || i == 2);
-                a.j[q] = TableAddJob{pack + tabs[i], M, ws + wl.head[i][0], M, want_stats ? st_h[i][0] : nullptr, M};
-                if (want_stats) parts_h[i][0] = a.slabs;
+                a.j[q] = TableAddJob{pack + tabs[i], M, ws + wl.head[i][0], M, ws + wl.head[i][0], M,
+                                     want_stats ? st_h[i][0] : nullptr, M, q * (M / 32)};
+                if (want_stats) parts_h[i][0] = M / 32;
             }
-            const int slabs = np * a.slabs;
+            const int slabs = np * (M / 32);
             int split = (cu_count() + slabs - 1) / slabs;
             if (split > (rows + 127) / 128) split = (rows + 127) / 128;
             ProfScope prof(PC_SAMPLE, s, (double)rows * L * M * np, 4.0 * np * (2.0 * rows * M + (double)L * 32 * M) + (double)rows * L);
