@@ -1175,7 +1175,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                     a.j[1] = TableAddJob{pack + pl.lin_zT, D, w->lin_b, 0, ws + wl.xz, D, nullptr, D, M / 32};
                     parts_a[0] = M / 32;
                     const int slabs = M / 32 + D / 32;
-                    int split = (cu_count() + slabs - 1) / slabs;
+                    int split = cu_count() / slabs > 0 ? cu_count() / slabs : 1;   // one workgroup per CU (128 KB of LDS each): a single round
                     if (split > (B + 127) / 128) split = (B + 127) / 128;
                     ProfScope prof(PC_SAMPLE, s, (double)B * L * (M + D), 4.0 * ((double)B * (3.0 * M + D) + (double)L * 32 * (M + D)) + (double)B * L);
                     k_table_add<<<dim3(slabs, split), dim3(1024), 0, s>>>(a);
@@ -1450,7 +1450,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 if (want_stats) parts_h[i][0] = M / 32;
             }
             const int slabs = np * (M / 32);
-            int split = (cu_count() + slabs - 1) / slabs;
+            int split = cu_count() / slabs > 0 ? cu_count() / slabs : 1;   // one workgroup per CU (128 KB of LDS each): a single round
             if (split > (rows + 127) / 128) split = (rows + 127) / 128;
             ProfScope prof(PC_SAMPLE, s, (double)rows * L * M * np, 4.0 * np * (2.0 * rows * M + (double)L * 32 * M) + (double)rows * L);
             k_table_add<<<dim3(slabs, split), dim3(1024), 0, s>>>(a);
