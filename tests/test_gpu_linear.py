@@ -116,3 +116,28 @@ def test_split_product_layout_and_table():
     y = N.fused_linear(xx.to(DEV), wd[:, :D], b.to(DEV), table=w_full[:, D:].T.contiguous().to(DEV),
                        zidx=idx.to(torch.uint8).to(DEV), split=True)
     assert float((y.cpu() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 100, 1056), (5, 33, 1028), (40, 257, 2048), (64, 48, 544), (1, 16, 4096), (23, 700, 520)])
+def test_few_rows_long_inner_dimension(M, N, K):
+    """At most 64 rows over an inner dimension beyond 512: the memory-bound matrix-core kernel (16-row tiles, K split over
+    the waves of a workgroup).  Ragged rows, columns that are no multiple of the 16-wide tile and inner dimensions that are
+    no multiple of its 64-wide blocks; fp32 to fp32 accumulation error, the bf16 form equal to the product of the rounded
+    operands (K a multiple of 8 or not: with and without the packed 16-byte reads)."""
+    from dreamer_amd import _native as N_
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = (x.double() @ w.double().T + b.double()).float()
+    y = N_.fused_linear(x.cuda(), w.cuda(), b.cuda()).cpu()
+    assert float((y - ref).abs().max() / ref.abs().max()) < 3e-6
+    yb = N_.fused_linear(x.cuda(), w.cuda(), b.cuda(), bf16=True).cpu()
+    ref_rounded = (x.bfloat16().double() @ w.bfloat16().double().T + b.double()).float()
+    assert float((yb - ref_rounded).abs().max() / ref_rounded.abs().max()) < 2e-5
+    # strided operands: a column window of a wider weight and of a wider input
+    wide_w = torch.randn(N, K + 64, generator=g).cuda()
+    wide_x = torch.randn(M, K + 32, generator=g).cuda()
+    y2 = N_.fused_linear(wide_x[:, 32:], wide_w[:, 64:], b.cuda()).cpu()
+    ref2 = (wide_x[:, 32:].double().cpu() @ wide_w[:, 64:].double().cpu().T + b.double()).float()
+    assert float((y2 - ref2).abs().max() / ref2.abs().max()) < 3e-6
