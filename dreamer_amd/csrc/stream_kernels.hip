@@ -15,15 +15,16 @@ __device__ __forceinline__ void stnt4(float* p, const float4& v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// lambda-return (lib/trainer.py:217-224).  One block owns ROWS consecutive trajectories: their R/C/V
-// values are one contiguous run of ROWS*H floats in each input, moved with 16-byte accesses, four per
+// lambda-return (lib/trainer.py:217-224).  One block of 256 threads owns ROWS consecutive trajectories: their
+// R/C/V values are one contiguous run of ROWS*H floats in each input, moved with 16-byte accesses, four per
 // array in flight per thread; the reverse scan itself runs from LDS, one lane per trajectory, with an odd
-// row stride so the 64 lanes of a wave hit different banks.  The two products that do not depend on the
+// row stride so the 64 lanes of a wave hit different banks.  ROWS shrinks as the horizon grows (256 down to 16
+// trajectories per block) so that the three staged arrays stay within 64 KB and two blocks share a CU.  The two products that do not depend on the
 // recurrence, gamma*(1-c) and (1-lambda)*v, are formed while loading; every operation is rounded on its
 // own, in the order of the eager fp32 expression, so results are bit-identical to the reference loop.
 // ------------------------------------------------------------------------------------------------
 template <int ROWS>
-__global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict__ R, const float* __restrict__ C,
+__global__ __launch_bounds__(256) void k_lambda_return(const float* __restrict__ R, const float* __restrict__ C,
                                                           const float* __restrict__ V,
                                                           const float* __restrict__ VL, float* __restrict__ out,
                                                           int64_t B, int H, float gamma, float one_minus_lam,
@@ -43,18 +44,18 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
     const float4* R4 = reinterpret_cast<const float4*>(R + base);
     const float4* C4 = reinterpret_cast<const float4*>(C + base);
     const float4* V4 = reinterpret_cast<const float4*>(V + base);
-    constexpr int U = 4;
-    for (int k0 = 0; k0 < n4; k0 += ROWS * U) {
+    constexpr int U = 4, NT = 256;
+    for (int k0 = 0; k0 < n4; k0 += NT * U) {
         float4 r[U], c[U], v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = min(k0 + u * ROWS + tid, n4 - 1);
+            const int i = min(k0 + u * NT + tid, n4 - 1);
             r[u] = ldnt4(reinterpret_cast<const float*>(R4 + i)); c[u] = ldnt4(reinterpret_cast<const float*>(C4 + i));
             v[u] = ldnt4(reinterpret_cast<const float*>(V4 + i));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = k0 + u * ROWS + tid;
+            const int i = k0 + u * NT + tid;
             if (i >= n4) continue;
             const float a4[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
             const float d4[4] = {__fmul_rn(gamma, __fsub_rn(1.0f, c[u].x)), __fmul_rn(gamma, __fsub_rn(1.0f, c[u].y)),
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
             }
         }
     }
-    for (int e = n4 * 4 + tid; e < n; e += ROWS) {       // unaligned inputs, or the last elements of a short tile
+    for (int e = n4 * 4 + tid; e < n; e += NT) {         // unaligned inputs, or the last elements of a short tile
         const int rr = e / H, pos = rr * HS + (e - rr * H);
         sA[pos] = R[base + e];
         sD[pos] = __fmul_rn(gamma, __fsub_rn(1.0f, C[base + e]));
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
     }
     __syncthreads();
     float4* O4 = reinterpret_cast<float4*>(out + base);
-    for (int i = tid; i < n4; i += ROWS) {
+    for (int i = tid; i < n4; i += NT) {
         if (HS == H) {
             stnt4(reinterpret_cast<float*>(O4 + i), reinterpret_cast<const float4*>(sA)[i]);
         } else {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(ROWS) void k_lambda_return(const float* __restrict_
             stnt4(reinterpret_cast<float*>(O4 + i), make_float4(o[0], o[1], o[2], o[3]));
         }
     }
-    for (int e = n4 * 4 + tid; e < n; e += ROWS) {
+    for (int e = n4 * 4 + tid; e < n; e += NT) {
         const int rr = e / H;
         out[base + e] = sA[rr * HS + (e - rr * H)];
     }
@@ -302,13 +303,18 @@ extern "C" int drm_lambda_return(const float* R, const float* C, const float* V,
     const float g = (float)gamma, oml = (float)(1.0 - lam), l = (float)lam;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(PC_LAMBDA, s, 6.0 * B * H, 16.0 * B * H + 4.0 * B);
-    const size_t sh = (size_t)3 * 256 * HS * 4;
-    if (sh <= 64 * 1024) {
-        const int vec = aligned16(R) && aligned16(C) && aligned16(V) && aligned16(out);
-        k_lambda_return<256><<<dim3((unsigned)((B + 255) / 256)), dim3(256), sh, s>>>(R, C, V, V_last, out, B, H, g, oml, l, vec);
-    } else {
+    const int vec = aligned16(R) && aligned16(C) && aligned16(V) && aligned16(out);
+    const size_t per_row = (size_t)3 * HS * 4;       // staged bytes per trajectory
+#define DRM_LAMBDA(ROWS) k_lambda_return<ROWS><<<dim3((unsigned)((B + ROWS - 1) / ROWS)), dim3(256), ROWS * per_row, s>>>(R, C, V, V_last, out, B, H, g, oml, l, vec)
+    if (256 * per_row <= 64 * 1024) DRM_LAMBDA(256);
+    else if (128 * per_row <= 64 * 1024) DRM_LAMBDA(128);
+    else if (64 * per_row <= 64 * 1024) DRM_LAMBDA(64);
+    else if (32 * per_row <= 64 * 1024) DRM_LAMBDA(32);
+    else if (16 * per_row <= 64 * 1024) DRM_LAMBDA(16);
+    else {
         k_lambda_return_chunked<<<dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s>>>(R, C, V, V_last, out, B, H, g, oml, l);
     }
+#undef DRM_LAMBDA
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
