@@ -25,7 +25,7 @@ def test_lambda_return_golden_bit_exact():
     assert torch.equal(out.cpu(), torch.from_numpy(g["lr_ret"]))
 
 
-@pytest.mark.parametrize("B,H", [(1, 1), (16, 15), (300, 15), (4096, 15), (7, 16), (33, 64), (5, 333)])
+@pytest.mark.parametrize("B,H", [(1, 1), (16, 15), (300, 15), (4096, 15), (7, 16), (33, 64), (5, 333), (70, 22), (37, 43), (130, 85), (19, 170), (70, 401)])
 def test_lambda_return_vs_oracle_bit_exact(B, H):
     R = torch.from_numpy(((hash_uniform("R", (B, H), B) - 0.5) * 6).astype(np.float32))
     C = torch.from_numpy(hash_uniform("C", (B, H), B).astype(np.float32))
