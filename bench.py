@@ -357,7 +357,10 @@ def main():
 
         def step():
             # draws the Exp(1) noise of the block (one generator call for both tensors) and runs the block
-            return eng.run(start, H, cfg.gamma, cfg.lam, start_zidx=zidx0, repack=repack, persistent=True, precision=precision)
+            # "f32" here names the fp32 matrix-instruction form explicitly (the engine's own default at 256 rows and more
+            # is the split form, measured as "f32_split")
+            return eng.run(start, H, cfg.gamma, cfg.lam, start_zidx=zidx0, repack=repack, persistent=True,
+                           precision="f32_mfma" if precision == "f32" else precision)
 
         for _ in range(warmup):
             step()
@@ -446,6 +449,8 @@ def main():
             c3[r["precision"]] = {"value": r["value"], "unit": "imagined latent steps/s", "ms_per_step": r["ms_per_step"],
                                   "steps": r["steps"], "warmup": r["warmup"], "B_per_gpu": r["B"], "H": H,
                                   "algorithmic_tflops": r["value"] * FLOP_PER_LATENT_STEP / 1e12, "roofline": r["roofline"]}
+        c3["note"] = ("f32: fp32 matrix instructions (v_mfma_f32_32x32x2_f32); f32_split: the same fp32-accurate products from an "
+                      "exact 3-way bf16 split on the bf16 matrix pipe, the engine's default form at 256 trajectories and more")
         extras["c3"] = c3
         torch.cuda.empty_cache()
 

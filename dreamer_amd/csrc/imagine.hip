@@ -830,9 +830,9 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         DRM_REQUIRE(q.X && q.W && q.Y && q.K >= 32 && q.K % 32 == 0 && q.N >= 1, DRM_EINVAL, "bad big problem");
         DRM_REQUIRE(aligned16(q.X) && aligned16(q.W) && q.ldx % 4 == 0 && q.ldw % 4 == 0, DRM_EINVAL, "misaligned operand");
         DRM_REQUIRE(!q.add && !q.rowscale, DRM_EINVAL, "large-row GEMM: no add / row-scale epilogue");
-        DRM_REQUIRE(!q.ln_g || (precision == 0 && q.ln_b && q.stats_in && q.parts_in >= 1 && q.parts_in <= 16), DRM_EINVAL,
-                    "large-row GEMM: LayerNorm on load needs the fp32 form and the row statistics (1..16 parts)");
-        DRM_REQUIRE(!q.stats_out || precision == 0, DRM_EINVAL, "large-row GEMM: row statistics come from the fp32 form only");
+        DRM_REQUIRE(!q.ln_g || (precision != 1 && q.ln_b && q.stats_in && q.parts_in >= 1 && q.parts_in <= 16), DRM_EINVAL,
+                    "large-row GEMM: LayerNorm on load needs the fp32 or the split form and the row statistics (1..16 parts)");
+        DRM_REQUIRE(!q.stats_out || precision != 1, DRM_EINVAL, "large-row GEMM: row statistics come from the fp32 and split forms only");
         DRM_REQUIRE(!q.tab || zidx, DRM_EINVAL, "gather table without indices");
         BigProblem& p = L.p[i];
         p.X = q.X; p.ldx = q.ldx; p.W = q.W; p.ldw = q.ldw; p.bias = q.bias; p.tab = q.tab; p.ldt = q.ldt;
@@ -840,7 +840,7 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         p.ln_g = q.ln_g; p.ln_b = q.ln_b; p.stats_in = q.stats_in; p.parts_in = q.parts_in; p.stats_out = q.stats_out;
         // slices per row of the statistics: 32 columns per accumulator column block when stored from the accumulators,
         // one per column tile through LDS (problems with a table)
-        p.parts_out = q.stats_out ? (q.tab ? (q.N + bn - 1) / bn : (q.N + bn / 2 - 1) / (bn / 2)) : 0;
+        p.parts_out = q.stats_out ? (q.tab || precision == 2 ? (q.N + bn - 1) / bn : (q.N + bn / 2 - 1) / (bn / 2)) : 0;
         specs[i].parts_out = p.parts_out;
         tiles += (q.N + bn - 1) / bn;
         const double n = q.N, k = q.K, m = M;
@@ -856,11 +856,14 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
     const dim3 grid(tiles, (M + BIG_BM - 1) / BIG_BM);
     if (precision == 1 && presplit) k_linear_big_bf16<true><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 1) k_linear_big_bf16<false><<<grid, dim3(256), 0, stream>>>(L);
-    else if (precision == 2 && presplit && narrow) k_linear_big_split<true, 1><<<grid, dim3(256), 0, stream>>>(L);
-    else if (precision == 2 && presplit) k_linear_big_split<true, 2><<<grid, dim3(256), 0, stream>>>(L);
-    else if (precision == 2 && narrow) k_linear_big_split<false, 1><<<grid, dim3(256), 0, stream>>>(L);
-    else if (precision == 2) k_linear_big_split<false, 2><<<grid, dim3(256), 0, stream>>>(L);
-    else {
+    else if (precision == 2) {
+        bool any_ln = false;
+        for (int i = 0; i < np; ++i) any_ln = any_ln || specs[i].ln_g != nullptr;
+#define DRM_SPLIT(PRE, NTV) { if (any_ln) k_linear_big_split<PRE, NTV, true><<<grid, dim3(256), 0, stream>>>(L); \
+                              else k_linear_big_split<PRE, NTV, false><<<grid, dim3(256), 0, stream>>>(L); }
+        if (presplit && narrow) DRM_SPLIT(true, 1) else if (presplit) DRM_SPLIT(true, 2) else if (narrow) DRM_SPLIT(false, 1) else DRM_SPLIT(false, 2)
+#undef DRM_SPLIT
+    } else {
         // fp32 form: a workgroup walks several tiles when no problem needs the epilogue through LDS and every K is an
         // even number (>= 4) of 32-deep steps; the grid is then what is resident at once
         L.ntx = (int)grid.x; L.nty = (int)grid.y;
@@ -1124,14 +1127,14 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
     const bool few = B <= SKINNY_MAX_ROWS && !wide;
     // fp32 products at many rows take the same launch sequence with the large-row kernel in place of the few-row one:
     // LayerNorm + SiLU applied by the consumer while it loads (row statistics left behind by the producer)
-    const bool fused = big && !wide && prec == 0 && std::getenv("DRM_NO_FUSED_STEP") == nullptr;
+    const bool fused = big && !wide && (prec == 0 || prec == 2) && std::getenv("DRM_NO_FUSED_STEP") == nullptr;
     // few rows of a wide model (hidden width still within the register-resident kernel): the same launch sequence; the
     // products over the recurrent width are memory-bound and run on the K-looped few-row kernel (bf16 weight images at
     // precision 1), the LayerNorm'd ones over the hidden width on the register-resident one
     const bool few_wide = B <= SKINNY_MAX_ROWS && wide && M <= 512 && prec != 2 && std::getenv("DRM_NO_FEW_WIDE") == nullptr;
     auto lin = [&](ProblemSpec* p, int np) -> int {
         if (few) return launch_skinny(p, np, B, s);
-        if (!few_wide) return launch_big(p, np, B, nullptr, 0, 0, 0, s, 0);
+        if (!few_wide) return launch_big(p, np, B, nullptr, 0, 0, 0, s, prec);
         for (int i = 0; i < np;) {
             const bool reg = p[i].K <= 512;
             int j = i + 1;
@@ -1431,7 +1434,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
         }
         if (np == 0) continue;
         if (fused) {
-            if (int rc = launch_big(p, np, rows, io->zidx_out, L, L, d.K, s, 0)) return rc;
+            if (int rc = launch_big(p, np, rows, io->zidx_out, L, L, d.K, s, prec)) return rc;
             for (int q = 0; q < np; ++q)
                 if (p[q].stats_out) parts_h[who[q]][dep & 1] = p[q].parts_out;
         } else {

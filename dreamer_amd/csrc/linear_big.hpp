@@ -547,7 +547,9 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
 // shared by every row tile and every step of a rollout), so only the activation operand is split here.
 // NT = 32-column accumulators per wave: 2 -> 64 x 128 tile, 1 -> 64 x 64 tile (launches whose 128-column grid would
 // put a single workgroup on a CU).
-template <bool PRESPLIT, int NT>
+// LNT: the consumer normalises, as in k_linear_big<., true> -- LayerNorm + SiLU of the X rows between the global load and
+// the split, from the row statistics the producer left behind (a problem without ln_g in the same launch loads as before).
+template <bool PRESPLIT, int NT, bool LNT>
 __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     constexpr int BN = 64 * NT;
     constexpr int A_PART = BIG_BM * BIG_LDH, B_PART = BN * BIG_LDH;
@@ -597,9 +599,34 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 rs0, rs1, rs2, rs3, rs4, rs5;
     rs0 = rs1 = rs2 = rs3 = rs4 = rs5 = (u32x4)(0u);
+    // row statistics of this thread's two staging rows: the 8 threads of a row fetch two parts each
+    const bool ln = LNT && P.ln_g != nullptr;
+    float mu[2] = {0.f, 0.f}, rsd[2] = {1.f, 1.f};
+    float4 rg = make_float4(0.f, 0.f, 0.f, 0.f), re = rg;
+    const float* gp = ln ? P.ln_g + skq : xa[0];
+    const float* ep = ln ? P.ln_b + skq : xa[0];
+    if (LNT) {
+        const float* st = ln ? P.stats_in : P.X;
+        const int np = ln ? P.parts_in : 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t row = ln ? (int64_t)min(m0 + srow + 32 * i, L.M - 1) : 0;
+            const int p0 = (tid & 7) * 2, p1 = p0 + 1;
+            const float2 a = *reinterpret_cast<const float2*>(st + (row * np + min(p0, np - 1)) * 2);
+            const float2 b = *reinterpret_cast<const float2*>(st + (row * np + min(p1, np - 1)) * 2);
+            const float sm = group_sum<8>((p0 < np ? a.x : 0.f) + (p1 < np ? b.x : 0.f));
+            const float sq = group_sum<8>((p0 < np ? a.y : 0.f) + (p1 < np ? b.y : 0.f));
+            const float mean = sm / (float)K;
+            mu[i] = mean; rsd[i] = 1.0f / sqrtf(fmaxf(sq / (float)K - mean * mean, 0.f) + LN_EPS);
+        }
+    }
 #define BIGS_LOAD(ko)                                                       \
     ra[0] = *reinterpret_cast<const float4*>(xa[0] + (ko));                 \
     ra[1] = *reinterpret_cast<const float4*>(xa[1] + (ko));                 \
+    if (LNT) {                                                              \
+        rg = *reinterpret_cast<const float4*>(gp + (ko));                   \
+        re = *reinterpret_cast<const float4*>(ep + (ko));                   \
+    }                                                                       \
     if (PRESPLIT) {                                                         \
         rs0 = *reinterpret_cast<const u32x4*>(ws0 + (ko));                \
         rs2 = *reinterpret_cast<const u32x4*>(ws0 + wplane + (ko));       \
@@ -649,6 +676,15 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 
     for (int ks = 0; ks < nk; ++ks) {
         if (ks > 0) __syncthreads();             // every wave has read the previous stage
+        if (LNT && ln) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i].x = big_silu((ra[i].x - mu[i]) * rsd[i] * rg.x + re.x);
+                ra[i].y = big_silu((ra[i].y - mu[i]) * rsd[i] * rg.y + re.y);
+                ra[i].z = big_silu((ra[i].z - mu[i]) * rsd[i] * rg.z + re.z);
+                ra[i].w = big_silu((ra[i].w - mu[i]) * rsd[i] * rg.w + re.w);
+            }
+        }
         BIGS_PUT(sA, srow, ra[0])
         BIGS_PUT(sA, srow + 32, ra[1])
         if (PRESPLIT) {

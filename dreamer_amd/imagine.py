@@ -12,6 +12,7 @@ change any value.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -131,9 +132,12 @@ class ImagineEngine:
         """Run the block.  With ``persistent=True`` all inputs are staged into, and all outputs
         returned as, buffers that live as long as the engine (overwritten by the next call with the
         same shape); every device address is then the same from call to call and the native side
-        replays the block as one recorded hipGraph.  ``precision="bf16"``: the matrix products of the
-        large-row path take bf16 inputs (fp32 accumulation, everything else fp32).  ``precision="f32_split"``:
-        those products at fp32 accuracy on the bf16 matrix pipe (exact three-way split of both operands).
+        replays the block as one recorded hipGraph.  ``precision="f32"`` (default): fp32 results to the rollout's
+        tolerance; from 256 trajectories on at widths up to 512 the matrix products are formed at fp32 accuracy on the bf16
+        matrix pipe (exact three-way split of both operands, the faster accurate form there), otherwise with fp32 matrix
+        instructions.  ``"f32_mfma"`` / ``"f32_split"`` ask for one of the two forms explicitly (``DRM_F32_MFMA=1`` makes
+        ``"f32"`` mean ``"f32_mfma"`` everywhere).  ``precision="bf16"``: the matrix products of the large-row path take
+        bf16 inputs (fp32 accumulation, everything else fp32).
         ``noalloc=True``: the library's entry point that takes no workspace (it uses a static device array of its own,
         for at most a few dozen trajectories) and never records a graph."""
         d, dev = self.dims, self.device
@@ -186,7 +190,10 @@ class ImagineEngine:
                                                        out["values"].data_ptr())
         io.v_last_out, io.lam_returns_out = out["v_last"].data_ptr(), out["lam_returns"].data_ptr()
         io.gamma, io.lam = float(gamma), float(lam)
-        io.precision = {"f32": 0, "bf16": 1, "f32_split": 2}[precision]
+        if precision == "f32":
+            split_wins = B >= 256 and d.D <= 512 and d.M <= 512 and os.environ.get("DRM_F32_MFMA", "0") != "1"
+            precision = "f32_split" if split_wins else "f32_mfma"
+        io.precision = {"f32_mfma": 0, "bf16": 1, "f32_split": 2}[precision]
         w = self._weights()
         if noalloc:
             io.workspace, io.workspace_bytes, io.use_graph = None, 0, 0

@@ -68,6 +68,13 @@ def test_teacher_forced_vs_oracle(B, H, A, layers):
     assert torch.equal(out["zidx"].cpu(), ref_zidx) and torch.equal(out["actions"].cpu(), ref["actions"])
     for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
         assert rel_err(out[key].cpu(), ref[key]) < TOL, key
+    if B >= 256:   # the default form there is the split one: the fp32 matrix-instruction form against the oracle as well
+        mf = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea.to(DEV), "z": ez.to(DEV)},
+                     forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV), want_prior_logits=True,
+                     precision="f32_mfma")
+        for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+            assert rel_err(mf[key].cpu(), ref[key]) < TOL, key
+        assert not torch.equal(mf["h"], out["h"])   # two different kernels ran
     # what the sampler drew must agree with the oracle wherever the draw is not a near-tie
     lp = O.log_unimix(ref["prior_logits"], 0.01) - ez.permute(1, 0, 2, 3).log()
     top2 = lp.topk(2, dim=-1).values
@@ -186,7 +193,7 @@ def test_split_products_meet_the_fp32_tolerance(B, H, D, M, L):
     kw = dict(noise={"a": ea.to(DEV), "z": ez.to(DEV)}, forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV),
               want_prior_logits=True)
     out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, precision="f32_split", **kw)
-    exact = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, **kw)
+    exact = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, precision="f32_mfma", **kw)
     torch.cuda.synchronize()
     differs = False
     for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
@@ -220,18 +227,21 @@ def _check_rows_against_oracle(wm, actor, critic, h0, z0, ea, ez, got, drew=True
     assert torch.equal(got["actions"][clear_a], ref["actions_sampled"][clear_a])
 
 
-def test_large_batch_properties():
-    """B = 4096 trajectories (the large-batch case): rows are independent, so any slice of the batch
-    must reproduce, bit for bit, what the same rows give when run alone."""
+@pytest.mark.parametrize("precision", ["f32", "f32_mfma"])
+def test_large_batch_properties(precision):
+    """B = 4096 trajectories (the large-batch case), in the default form of the fp32 products there (split) and in the
+    fp32 matrix-instruction form: rows are independent, so any slice of the batch must reproduce, bit for bit, what the
+    same rows give when run alone."""
     d, salt, B, H = DIMS["default"], 5, 4096, 15
     wm, actor, critic, eng = _engine(d, salt)
     h0, z0, _ = start_state(d, salt, B)
     ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt)).to(DEV)
     ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt)).to(DEV)
-    full = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False)
+    full = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False,
+                   precision=precision)
     rows = slice(1000, 1300)   # 300 rows: still the large-row kernels, different tile positions
     part = eng.run(WorldModelState(h=h0[rows].to(DEV), z=z0[rows].to(DEV)), H, 0.997, 0.95,
-                   noise={"a": ea[:, rows].contiguous(), "z": ez[:, rows].contiguous()}, want_dense_z=False)
+                   noise={"a": ea[:, rows].contiguous(), "z": ez[:, rows].contiguous()}, want_dense_z=False, precision=precision)
     torch.cuda.synchronize()
     for key in ("h", "zidx", "actions", "rewards", "conts", "values", "lam_returns"):
         assert torch.equal(full[key][rows].cpu(), part[key].cpu()), key
@@ -258,7 +268,7 @@ def test_large_batch_split_products_follow_the_fp32_form():
     ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt)).to(DEV)
     ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt)).to(DEV)
     st = WorldModelState(h=h0.to(DEV), z=z0.to(DEV))
-    base = eng.run(st, H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False)
+    base = eng.run(st, H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False, precision="f32_mfma")
     split = eng.run(st, H, 0.997, 0.95, noise={"a": ea, "z": ez}, want_dense_z=False, precision="f32_split",
                     forced_actions=base["actions"].contiguous(), forced_zidx=base["zidx"].contiguous())
     torch.cuda.synchronize()
