@@ -931,7 +931,11 @@ struct WsLayout {
     size_t st_a[2], st_d[2], st_h[3][2];   // row statistics (32 floats per row) of the fp32 large-row path
 };
 constexpr int BIG_MIN_ROWS = 256;   // from this many trajectories on, the MFMA-bound large-row kernels are used
-constexpr int TWO_CHAINS_MIN_ROWS = 2048;   // from this many on, two half-batch chains of launches side by side
+constexpr int TWO_CHAINS_MIN_ROWS = 512;    // workspaces are sized for two chains from here on
+static int two_chains_min_rows() {          // from this many trajectories on, two half-batch chains of launches side by side
+    static const int v = [] { const char* e = std::getenv("DRM_TWO_CHAINS_MIN_ROWS"); const int n = e ? atoi(e) : 2048; return n < 512 ? 512 : n; }();
+    return v;
+}
 static WsLayout ws_layout(const drm_dims& d, int B, int H) {
     WsLayout w{};
     size_t o = 0;
@@ -1496,7 +1500,7 @@ static int chain_count(int B) {
     return n;
 }
 static bool two_chains_ok(int B) {
-    return B >= TWO_CHAINS_MIN_ROWS && B % 128 == 0 && !prof_on() && std::getenv("DRM_NO_TWO_CHAINS") == nullptr;
+    return B >= two_chains_min_rows() && B % 128 == 0 && !prof_on() && std::getenv("DRM_NO_TWO_CHAINS") == nullptr;
 }
 }  // namespace drm
 

@@ -595,10 +595,12 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     __bf16* const wdst = &sB[0][prow][pkq];
 
     const int nk = K / BIG_BK;
-    float4 ra[2], rb[4];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 rs0, rs1, rs2, rs3, rs4, rs5;
-    rs0 = rs1 = rs2 = rs3 = rs4 = rs5 = (u32x4)(0u);
+    // two register stages of global loads (stage = K-step parity): a K-step's operands are requested two steps ahead
+    float4 raA[2], raB[2], rbA[4], rbB[4];
+    u32x4 rsA[6], rsB[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { rsA[i] = (u32x4)(0u); rsB[i] = (u32x4)(0u); }
     // row statistics of this thread's two staging rows: the 8 threads of a row fetch two parts each
     const bool ln = LNT && P.ln_g != nullptr;
     float mu[2] = {0.f, 0.f}, rsd[2] = {1.f, 1.f};
@@ -620,28 +622,34 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
             mu[i] = mean; rsd[i] = 1.0f / sqrtf(fmaxf(sq / (float)K - mean * mean, 0.f) + LN_EPS);
         }
     }
-#define BIGS_LOAD(ko)                                                       \
-    ra[0] = *reinterpret_cast<const float4*>(xa[0] + (ko));                 \
-    ra[1] = *reinterpret_cast<const float4*>(xa[1] + (ko));                 \
+    // loads are unconditional (past the end they re-read the last step)
+#define BIGS_LOADG(ks_)                                                     \
     if (LNT) {                                                              \
-        rg = *reinterpret_cast<const float4*>(gp + (ko));                   \
-        re = *reinterpret_cast<const float4*>(ep + (ko));                   \
-    }                                                                       \
-    if (PRESPLIT) {                                                         \
-        rs0 = *reinterpret_cast<const u32x4*>(ws0 + (ko));                \
-        rs2 = *reinterpret_cast<const u32x4*>(ws0 + wplane + (ko));       \
-        rs4 = *reinterpret_cast<const u32x4*>(ws0 + 2 * wplane + (ko));   \
-        if (NT == 2) {                                                      \
-            rs1 = *reinterpret_cast<const u32x4*>(ws1 + (ko));            \
-            rs3 = *reinterpret_cast<const u32x4*>(ws1 + wplane + (ko));   \
-            rs5 = *reinterpret_cast<const u32x4*>(ws1 + 2 * wplane + (ko)); \
-        }                                                                   \
-    } else {                                                                \
-        rb[0] = *reinterpret_cast<const float4*>(wb[0] + (ko));             \
-        rb[1] = *reinterpret_cast<const float4*>(wb[1] + (ko));             \
-        if (NT == 2) {                                                      \
-            rb[2] = *reinterpret_cast<const float4*>(wb[2] + (ko));         \
-            rb[3] = *reinterpret_cast<const float4*>(wb[3] + (ko));         \
+        const int ko_ = min((ks_), nk - 1) * BIG_BK;                        \
+        rg = *reinterpret_cast<const float4*>(gp + ko_);                    \
+        re = *reinterpret_cast<const float4*>(ep + ko_);                    \
+    }
+#define BIGS_LOAD(S, ks_)                                                   \
+    {                                                                       \
+        const int ko = min((ks_), nk - 1) * BIG_BK;                         \
+        ra##S[0] = *reinterpret_cast<const float4*>(xa[0] + ko);            \
+        ra##S[1] = *reinterpret_cast<const float4*>(xa[1] + ko);            \
+        if (PRESPLIT) {                                                     \
+            rs##S[0] = *reinterpret_cast<const u32x4*>(ws0 + ko);           \
+            rs##S[2] = *reinterpret_cast<const u32x4*>(ws0 + wplane + ko);  \
+            rs##S[4] = *reinterpret_cast<const u32x4*>(ws0 + 2 * wplane + ko); \
+            if (NT == 2) {                                                  \
+                rs##S[1] = *reinterpret_cast<const u32x4*>(ws1 + ko);       \
+                rs##S[3] = *reinterpret_cast<const u32x4*>(ws1 + wplane + ko); \
+                rs##S[5] = *reinterpret_cast<const u32x4*>(ws1 + 2 * wplane + ko); \
+            }                                                               \
+        } else {                                                            \
+            rb##S[0] = *reinterpret_cast<const float4*>(wb[0] + ko);        \
+            rb##S[1] = *reinterpret_cast<const float4*>(wb[1] + ko);        \
+            if (NT == 2) {                                                  \
+                rb##S[2] = *reinterpret_cast<const float4*>(wb[2] + ko);    \
+                rb##S[3] = *reinterpret_cast<const float4*>(wb[3] + ko);    \
+            }                                                               \
         }                                                                   \
     }
 #define BIGS_PUT(S, row, v)                                                 \
@@ -668,65 +676,77 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 #define BIGS_SIX(ah, am, al, b0h, b0m, b0l)                                 \
     BIGS_MMA(am, b0m, acc0) BIGS_MMA(al, b0h, acc0) BIGS_MMA(ah, b0l, acc0) \
     BIGS_MMA(am, b0h, acc0) BIGS_MMA(ah, b0m, acc0) BIGS_MMA(ah, b0h, acc0)
+    // one K-step from register stage S: LDS <- registers (normalised, split), then the requests for the step after next
+    // (the LayerNorm parameters of the next step first: they are needed one step earlier than the stage's operands)
+#define BIGS_STEP(S, ks_)                                                   \
+    {                                                                       \
+        if ((ks_) > 0) __syncthreads();          /* every wave has read the previous stage */ \
+        if (LNT && ln) {                                                    \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                 \
+                ra##S[i].x = big_silu((ra##S[i].x - mu[i]) * rsd[i] * rg.x + re.x); \
+                ra##S[i].y = big_silu((ra##S[i].y - mu[i]) * rsd[i] * rg.y + re.y); \
+                ra##S[i].z = big_silu((ra##S[i].z - mu[i]) * rsd[i] * rg.z + re.z); \
+                ra##S[i].w = big_silu((ra##S[i].w - mu[i]) * rsd[i] * rg.w + re.w); \
+            }                                                               \
+        }                                                                   \
+        BIGS_PUT(sA, srow, ra##S[0])                                        \
+        BIGS_PUT(sA, srow + 32, ra##S[1])                                   \
+        if (PRESPLIT) {                                                     \
+            *reinterpret_cast<u32x4*>(wdst) = rs##S[0];                     \
+            *reinterpret_cast<u32x4*>(wdst + B_PART) = rs##S[2];            \
+            *reinterpret_cast<u32x4*>(wdst + 2 * B_PART) = rs##S[4];        \
+            if (NT == 2) {                                                  \
+                *reinterpret_cast<u32x4*>(wdst + 64 * BIG_LDH) = rs##S[1];  \
+                *reinterpret_cast<u32x4*>(wdst + B_PART + 64 * BIG_LDH) = rs##S[3]; \
+                *reinterpret_cast<u32x4*>(wdst + 2 * B_PART + 64 * BIG_LDH) = rs##S[5]; \
+            }                                                               \
+        } else {                                                            \
+            BIGS_PUT(sB, srow, rb##S[0])                                    \
+            BIGS_PUT(sB, srow + 32, rb##S[1])                               \
+            if (NT == 2) {                                                  \
+                BIGS_PUT(sB, srow + 64, rb##S[2])                           \
+                BIGS_PUT(sB, srow + 96, rb##S[3])                           \
+            }                                                               \
+        }                                                                   \
+        __syncthreads();                                                    \
+        BIGS_LOADG((ks_) + 1)                                               \
+        BIGS_LOAD(S, (ks_) + 2)                                             \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {            \
+            const bf16x8 ah = BIGS_FRAG(sA, 0, wm * 32 + li, half), am = BIGS_FRAG(sA, 1, wm * 32 + li, half), \
+                         al = BIGS_FRAG(sA, 2, wm * 32 + li, half);         \
+            const bf16x8 b0h = BIGS_FRAG(sB, 0, wn * 32 * NT + li, half), b0m = BIGS_FRAG(sB, 1, wn * 32 * NT + li, half), \
+                         b0l = BIGS_FRAG(sB, 2, wn * 32 * NT + li, half);   \
+            if (NT == 2) {                                                  \
+                const bf16x8 b1h = BIGS_FRAG(sB, 0, wn * 64 + 32 + li, half), b1m = BIGS_FRAG(sB, 1, wn * 64 + 32 + li, half), \
+                             b1l = BIGS_FRAG(sB, 2, wn * 64 + 32 + li, half); \
+                BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)       \
+            } else {                                                        \
+                BIGS_SIX(ah, am, al, b0h, b0m, b0l)                         \
+            }                                                               \
+        }                                                                   \
+    }
 
-    BIGS_LOAD(0)
+    BIGS_LOADG(0)
+    BIGS_LOAD(A, 0)
+    BIGS_LOAD(B, 1)
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
-    for (int ks = 0; ks < nk; ++ks) {
-        if (ks > 0) __syncthreads();             // every wave has read the previous stage
-        if (LNT && ln) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ra[i].x = big_silu((ra[i].x - mu[i]) * rsd[i] * rg.x + re.x);
-                ra[i].y = big_silu((ra[i].y - mu[i]) * rsd[i] * rg.y + re.y);
-                ra[i].z = big_silu((ra[i].z - mu[i]) * rsd[i] * rg.z + re.z);
-                ra[i].w = big_silu((ra[i].w - mu[i]) * rsd[i] * rg.w + re.w);
-            }
-        }
-        BIGS_PUT(sA, srow, ra[0])
-        BIGS_PUT(sA, srow + 32, ra[1])
-        if (PRESPLIT) {
-            *reinterpret_cast<u32x4*>(wdst) = rs0;
-            *reinterpret_cast<u32x4*>(wdst + B_PART) = rs2;
-            *reinterpret_cast<u32x4*>(wdst + 2 * B_PART) = rs4;
-            if (NT == 2) {
-                *reinterpret_cast<u32x4*>(wdst + 64 * BIG_LDH) = rs1;
-                *reinterpret_cast<u32x4*>(wdst + B_PART + 64 * BIG_LDH) = rs3;
-                *reinterpret_cast<u32x4*>(wdst + 2 * B_PART + 64 * BIG_LDH) = rs5;
-            }
-        } else {
-            BIGS_PUT(sB, srow, rb[0])
-            BIGS_PUT(sB, srow + 32, rb[1])
-            if (NT == 2) {
-                BIGS_PUT(sB, srow + 64, rb[2])
-                BIGS_PUT(sB, srow + 96, rb[3])
-            }
-        }
-        __syncthreads();
-        if (ks + 1 < nk) { BIGS_LOAD((ks + 1) * BIG_BK) }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const bf16x8 ah = BIGS_FRAG(sA, 0, wm * 32 + li, half), am = BIGS_FRAG(sA, 1, wm * 32 + li, half),
-                         al = BIGS_FRAG(sA, 2, wm * 32 + li, half);
-            const bf16x8 b0h = BIGS_FRAG(sB, 0, wn * 32 * NT + li, half), b0m = BIGS_FRAG(sB, 1, wn * 32 * NT + li, half),
-                         b0l = BIGS_FRAG(sB, 2, wn * 32 * NT + li, half);
-            if (NT == 2) {
-                const bf16x8 b1h = BIGS_FRAG(sB, 0, wn * 64 + 32 + li, half), b1m = BIGS_FRAG(sB, 1, wn * 64 + 32 + li, half),
-                             b1l = BIGS_FRAG(sB, 2, wn * 64 + 32 + li, half);
-                BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)
-            } else {
-                BIGS_SIX(ah, am, al, b0h, b0m, b0l)
-            }
-        }
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {               // no branch inside: a branch around a step's loads makes every wait a full one
+        BIGS_STEP(A, ks)
+        BIGS_STEP(B, ks + 1)
     }
+    if (nk & 1) BIGS_STEP(A, ks)
+#undef BIGS_LOADG
 #undef BIGS_LOAD
 #undef BIGS_PUT
 #undef BIGS_FRAG
 #undef BIGS_MMA
 #undef BIGS_TWELVE
 #undef BIGS_SIX
+#undef BIGS_STEP
 
     // ---- epilogue (as k_linear_big): tile through LDS, + bias, + one-hot table rows, 16-byte stores
     __syncthreads();
