@@ -242,7 +242,7 @@ def measure_acting(learner, device, rng, steps=300):
 
 
 def measure_scaled_model(device, steps=4):
-    """BASELINE config 5 on one GPU: D = 4096, 32 x 32 categorical latent, 64 x 64 frames; random weights and inputs."""
+    """The scaled model on one GPU: D = 4096, 32 x 32 categorical latent, 64 x 64 frames; random weights and inputs."""
     from dreamer_amd.actor import Actor
     from dreamer_amd.critic import Critic
     from dreamer_amd.imagine import ImagineEngine
