@@ -190,7 +190,9 @@ int drm_copy_pair(const void* a_src, void* a_dst, size_t a_bytes, const void* b_
  *   normalisation applied by the consumer of the raw pre-activations);
  *   the table term (optional) is the one-hot part of a Linear over cat[h, z_flat]
  *   (lib/world_model.py:213-215) written as a row gather.
- * W is (N,K) row-major with row stride ldw (torch Linear layout).  K % 32 == 0, K <= 512. */
+ * W is (N,K) row-major with row stride ldw (torch Linear layout).  K % 32 == 0, K <= 4096; K <= 512 with the
+ * LayerNorm prologue.  Without prologue and table, at most 64 rows over K > 512 take any K that is a multiple of 4
+ * (a memory-bound kernel on 16-row matrix-core tiles: the products of a wide model at the default batch). */
 typedef struct drm_linear_args {
     const float* X; int64_t ldx;
     const float* ln_gamma; const float* ln_beta;
@@ -308,7 +310,9 @@ typedef struct drm_imagine_io {
                                       (B >= 256 or widths > 512) take bf16 inputs with fp32 accumulation;
                                       LayerNorm, gates, sampling and the lambda-return stay fp32.
                                       2: those products at fp32 accuracy from an exact three-way bf16 split
-                                      of both operands (see drm_fused_linear_split) */
+                                      of both operands (see drm_fused_linear_split); at widths up to 512 the
+                                      faster of the two fp32-accurate forms from 256 trajectories on (the Python
+                                      engine's default there) */
 } drm_imagine_io;
 
 size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H);
