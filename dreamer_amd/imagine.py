@@ -33,6 +33,21 @@ def _mlp_struct(mlp, head, in_dim: int) -> N.drm_mlp:
     return s
 
 
+def resolve_precision(precision: str, trajectories: int, recurrent_width: int, hidden_width: int) -> int:
+    """The library's ``precision`` code (0 fp32 matrix instructions, 1 bf16 matrix inputs, 2 exact three-way bf16 split) for a
+    precision name.  ``"f32"`` asks for fp32 results and leaves the form to the engine: the split form from 256
+    trajectories on at widths up to 512 (the faster fp32-accurate form there; ``DRM_F32_MFMA=1`` disables the choice),
+    fp32 matrix instructions otherwise."""
+    if precision == "f32":
+        split_wins = (trajectories >= 256 and recurrent_width <= 512 and hidden_width <= 512
+                      and os.environ.get("DRM_F32_MFMA", "0") != "1")
+        precision = "f32_split" if split_wins else "f32_mfma"
+    try:
+        return {"f32_mfma": 0, "bf16": 1, "f32_split": 2}[precision]
+    except KeyError:
+        raise ValueError(f"unknown precision {precision!r}: expected 'f32', 'f32_mfma', 'f32_split' or 'bf16'") from None
+
+
 class ImagineEngine:
     """Owns the packed gather tables and the workspace for one (world model, actor, critic) triple."""
 
@@ -190,10 +205,7 @@ class ImagineEngine:
                                                        out["values"].data_ptr())
         io.v_last_out, io.lam_returns_out = out["v_last"].data_ptr(), out["lam_returns"].data_ptr()
         io.gamma, io.lam = float(gamma), float(lam)
-        if precision == "f32":
-            split_wins = B >= 256 and d.D <= 512 and d.M <= 512 and os.environ.get("DRM_F32_MFMA", "0") != "1"
-            precision = "f32_split" if split_wins else "f32_mfma"
-        io.precision = {"f32_mfma": 0, "bf16": 1, "f32_split": 2}[precision]
+        io.precision = resolve_precision(precision, B, d.D, d.M)
         w = self._weights()
         if noalloc:
             io.workspace, io.workspace_bytes, io.use_graph = None, 0, 0

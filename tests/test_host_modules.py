@@ -140,3 +140,23 @@ def test_act_step_is_the_state_of_step(with_cont):
     torch.testing.assert_close(got.h, ref.h, rtol=1e-5, atol=1e-6)
     assert torch.equal(got.z, ref.z)
     assert torch.equal(after_ref, after_got)
+
+
+def test_precision_names_resolve_to_library_codes(monkeypatch):
+    """``"f32"`` leaves the form of the fp32-accurate products to the engine: the split form from 256 trajectories on at the
+    default widths, fp32 matrix instructions for few trajectories and for wide models; explicit names are taken as given."""
+    from dreamer_amd.imagine import resolve_precision
+    monkeypatch.delenv("DRM_F32_MFMA", raising=False)
+    assert resolve_precision("f32", 16, 512, 512) == 0
+    assert resolve_precision("f32", 255, 512, 512) == 0
+    assert resolve_precision("f32", 256, 512, 512) == 2
+    assert resolve_precision("f32", 4096, 512, 512) == 2
+    assert resolve_precision("f32", 4096, 4096, 512) == 0          # wide recurrent state
+    assert resolve_precision("f32", 4096, 512, 1024) == 0          # wide hidden layers
+    assert resolve_precision("f32_mfma", 4096, 512, 512) == 0
+    assert resolve_precision("f32_split", 16, 512, 512) == 2
+    assert resolve_precision("bf16", 16, 4096, 512) == 1
+    monkeypatch.setenv("DRM_F32_MFMA", "1")
+    assert resolve_precision("f32", 4096, 512, 512) == 0
+    with pytest.raises(ValueError):
+        resolve_precision("fp16", 16, 512, 512)
