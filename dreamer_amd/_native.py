@@ -186,6 +186,17 @@ def require_cuda(*tensors: torch.Tensor) -> None:
             raise NativeError("this operation runs only on a HIP device tensor")
 
 
+def _extent(t: torch.Tensor) -> int:
+    """Bytes between the tensor's first element and the end of the storage it lives in."""
+    return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+
+
+def _require_bytes(t: Optional[torch.Tensor], nbytes: int, name: str) -> None:
+    """The kernel behind a wrapper addresses ``nbytes`` from ``t``'s first element: refuse the call when the storage is shorter."""
+    if t is not None and _extent(t) < nbytes:
+        raise NativeError(f"{name}: the kernel addresses {nbytes} bytes, the tensor's storage holds {_extent(t)} from its first element")
+
+
 def _dense(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if t.dtype != dtype or not t.is_contiguous():
         raise NativeError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
@@ -250,6 +261,11 @@ def ln_silu_forward(x, gamma, beta, eps: float, channel_bias=None):
     if channel_bias is not None:
         _dense(channel_bias, torch.float32, "channel_bias")
         hw = E // channel_bias.numel()
+    if x.numel() != N * E:
+        raise NativeError(f"ln_silu_forward: x has {x.numel()} elements, expected {N} samples of {E}")
+    if channel_bias is not None and (E % channel_bias.numel() or (cl and channel_bias.numel() != x.shape[1])):
+        raise NativeError("ln_silu_forward: channel bias does not match the sample shape")
+    _require_bytes(beta, 4 * E, "beta")
     y = torch.empty_like(x)
     mean = torch.empty(N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N, dtype=torch.float32, device=x.device)
@@ -267,6 +283,10 @@ def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None, want_dx_
     if _dense_or_cl(dy, "dy") != cl:
         raise ValueError("dy must have the memory format of x")
     N, E = x.shape[0], gamma.numel()
+    if x.numel() != N * E or dy.numel() != N * E or beta.numel() != E or mean.numel() < N or rstd.numel() < N:
+        raise NativeError(f"ln_silu_backward: operand sizes do not match {N} samples of {E}")
+    if channel_bias is not None and (E % channel_bias.numel() or (cl and channel_bias.numel() != x.shape[1])):
+        raise NativeError("ln_silu_backward: channel bias does not match the sample shape")
     slices = lib().drm_ln_silu_slices(N, E)
     dx = torch.empty_like(x)
     rows = 2 if (channel_bias is None and not want_dx_sum) else 3
@@ -315,6 +335,8 @@ def convt_k4s2_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     _dense(x, torch.float32, "x"); _dense(weight, torch.float32, "weight")
     n, cin, h, w = x.shape
     cout = weight.shape[1]
+    if tuple(weight.shape) != (cin, cout, 4, 4) or (bias is not None and (bias.numel() != cout or bias.dtype != torch.float32)):
+        raise NativeError(f"convt_k4s2_forward: weight {tuple(weight.shape)} / bias do not match {cin} input channels")
     y = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
     check(lib().drm_convt_k4s2_forward(x.data_ptr(), weight.data_ptr(), ptr(bias), y.data_ptr(), n, cin, cout, h, w,
                                        stream_ptr(x.device)), "drm_convt_k4s2_forward")
@@ -328,6 +350,8 @@ def convt_k4s2_input_grad(grad_y: torch.Tensor, weight: torch.Tensor, channels_l
     _dense(grad_y, torch.float32, "grad_y"); _dense(weight, torch.float32, "weight")
     n, cout, ho, wo = grad_y.shape
     cin = weight.shape[0]
+    if tuple(weight.shape) != (cin, cout, 4, 4) or ho % 2 or wo % 2:
+        raise NativeError(f"convt_k4s2_input_grad: weight {tuple(weight.shape)} does not match a gradient of shape {tuple(grad_y.shape)}")
     channels_last = bool(channels_last) and cin % 4 == 0
     gx = torch.empty((n, cin, ho // 2, wo // 2), dtype=torch.float32, device=grad_y.device,
                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
@@ -357,6 +381,17 @@ def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int =
     N = w.shape[0]
     if w_cols is not None:
         assert w_cols == K
+    if x.dim() != 2 or w.dim() != 2 or w.shape[1] < K or x.stride(1) != 1 or w.stride(1) != 1 or x.dtype != torch.float32 \
+            or w.dtype != torch.float32:
+        raise NativeError("fused_linear: x (M, K) and w (N, >= K) must be fp32 matrices with contiguous rows")
+    _require_bytes(bias, 4 * N, "bias")
+    if ln is not None:
+        _require_bytes(ln[0], 4 * K, "ln gamma"); _require_bytes(ln[1], 4 * K, "ln beta")
+    if table is not None:
+        if zidx is None or zidx.dtype != torch.uint8 or zidx.dim() != 2 or zidx.shape[0] != M or zidx.stride(1) != 1:
+            raise NativeError("fused_linear: a gather table needs uint8 class indices (M, latents)")
+        if table.dim() != 2 or table.shape[0] < zidx.shape[1] * classes or table.shape[1] < N or table.stride(1) != 1:
+            raise NativeError("fused_linear: the gather table must be (latents * classes, >= N)")
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     a = drm_linear_args()
     a.X, a.ldx = x.data_ptr(), x.stride(0)
@@ -418,6 +453,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     Kb, N = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
     if K != Kb:
         raise ValueError(f"gemm: reduction extents differ ({K} vs {Kb})")
+    if not gemm_ok(a, b, trans_a, trans_b):
+        raise NativeError("gemm: operands must be fp32 device matrices with contiguous, 16-byte aligned rows")
+    if bias is not None:
+        _dense(bias, torch.float32, "bias")
+        _require_bytes(bias, 4 * N, "bias")
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
     need = lib().drm_gemm_workspace_bytes(M, N, K)
     ws = None
@@ -454,6 +494,8 @@ def conv4s2_down(big: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     big, kernel = _cl4(big, "big"), _cl4(kernel, "kernel")
     ni, cb, hb, wb = big.shape
     cs = kernel.shape[0]
+    if tuple(kernel.shape) != (cs, cb, 4, 4) or hb % 2 or wb % 2:
+        raise NativeError(f"conv4s2_down: kernel {tuple(kernel.shape)} does not fit an input of shape {tuple(big.shape)} (even height and width)")
     out = torch.empty((ni, cs, hb // 2, wb // 2), dtype=torch.float32, device=big.device, memory_format=torch.channels_last)
     check(lib().drm_conv4s2_down(big.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hb // 2, wb // 2, cs, cb,
                                  stream_ptr(big.device)), "drm_conv4s2_down")
@@ -465,6 +507,8 @@ def conv4s2_up(small: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     small, kernel = _cl4(small, "small"), _cl4(kernel, "kernel")
     ni, cs, hs, ws = small.shape
     cb = kernel.shape[1]
+    if tuple(kernel.shape) != (cs, cb, 4, 4):
+        raise NativeError(f"conv4s2_up: kernel {tuple(kernel.shape)} does not fit an input of shape {tuple(small.shape)}")
     out = torch.empty((ni, cb, 2 * hs, 2 * ws), dtype=torch.float32, device=small.device, memory_format=torch.channels_last)
     check(lib().drm_conv4s2_up(small.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, stream_ptr(small.device)),
           "drm_conv4s2_up")
@@ -477,6 +521,8 @@ def conv4s2_wgrad(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
     small, big = _cl4(small, "small"), _cl4(big, "big")
     ni, cs, hs, ws = small.shape
     cb = big.shape[1]
+    if tuple(big.shape) != (ni, cb, 2 * hs, 2 * ws):
+        raise NativeError(f"conv4s2_wgrad: shapes {tuple(small.shape)} and {tuple(big.shape)} are not the two sides of one stride-2 layer")
     out = torch.empty((cs, cb, 4, 4), dtype=torch.float32, device=small.device, memory_format=torch.channels_last)
     need = lib().drm_conv4s2_wgrad_workspace_bytes(ni, hs, ws, cs, cb)
     ws_t = None

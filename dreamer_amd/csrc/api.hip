@@ -1,6 +1,7 @@
 // Library-level entry points: version, error text, architecture check.
 #include "common.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -8,6 +9,16 @@
 namespace drm {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+
+int launch_check(const char* func, const char* file, int line) {
+    static const bool sync = [] { const char* e = std::getenv("DRM_SYNC_CHECK"); return e != nullptr && e[0] != '0'; }();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && sync) e = hipDeviceSynchronize();
+    if (e == hipSuccess) return DRM_OK;
+    set_error(std::string(func) + ": launch at " + file + ":" + std::to_string(line) + " -> " + hipGetErrorString(e));
+    if (sync) fprintf(stderr, "[drm] %s: launch at %s:%d failed: %s\n", func, file, line, hipGetErrorString(e));
+    return DRM_EHIP;
+}
 }  // namespace drm
 
 namespace drm {

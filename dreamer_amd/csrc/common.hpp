@@ -30,7 +30,14 @@ void set_error(const std::string& msg);
         }                                                                                  \
     } while (0)
 
-#define DRM_LAUNCH_CHECK() DRM_HIP(hipGetLastError())
+// After every kernel launch.  With DRM_SYNC_CHECK=1 in the environment the device is synchronised behind each launch and a
+// failure is reported on stderr with the launch site, so an asynchronous memory fault names the kernel that caused it
+// (diagnostic mode: serialises everything).
+int launch_check(const char* func, const char* file, int line);
+#define DRM_LAUNCH_CHECK()                                                       \
+    do {                                                                         \
+        if (int _rc = ::drm::launch_check(__func__, __FILE__, __LINE__)) return _rc; \
+    } while (0)
 
 // kernel classes for the optional per-launch timing
 enum ProfClass { PC_LINEAR = 0, PC_GRU, PC_DYN_SAMPLE, PC_ACTOR_HEAD, PC_SCALAR_HEADS, PC_CRITIC_VALUE, PC_LAMBDA,
