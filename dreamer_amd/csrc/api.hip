@@ -11,8 +11,12 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
 int launch_check(const char* func, const char* file, int line) {
-    static const bool sync = [] { const char* e = std::getenv("DRM_SYNC_CHECK"); return e != nullptr && e[0] != '0'; }();
+    static const int mode = [] { const char* e = std::getenv("DRM_SYNC_CHECK"); return e != nullptr ? atoi(e) : 0; }();
+    const bool sync = mode != 0;
     hipError_t e = hipGetLastError();
+    // mode 2: the launch site goes to stderr before the wait, so that a memory fault (which ends the process inside the
+    // wait) leaves the name of its kernel's launch as the last line
+    if (mode >= 2) { fprintf(stderr, "[drm] launched %s at %s:%d\n", func, file, line); fflush(stderr); }
     if (e == hipSuccess && sync) e = hipDeviceSynchronize();
     if (e == hipSuccess) return DRM_OK;
     set_error(std::string(func) + ": launch at " + file + ":" + std::to_string(line) + " -> " + hipGetErrorString(e));

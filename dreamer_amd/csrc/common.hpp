@@ -32,7 +32,7 @@ void set_error(const std::string& msg);
 
 // After every kernel launch.  With DRM_SYNC_CHECK=1 in the environment the device is synchronised behind each launch and a
 // failure is reported on stderr with the launch site, so an asynchronous memory fault names the kernel that caused it
-// (diagnostic mode: serialises everything).
+// (diagnostic mode: serialises everything); DRM_SYNC_CHECK=2 also prints every launch site before waiting for it.
 int launch_check(const char* func, const char* file, int line);
 #define DRM_LAUNCH_CHECK()                                                       \
     do {                                                                         \

@@ -342,6 +342,17 @@ class _Tower(nn.Sequential):
     # training update: 11.13 ms against 11.66 ms with plain NCHW tensors (DRM_TOWER_CHANNELS_LAST=0).
     channels_last = os.environ.get("DRM_TOWER_CHANNELS_LAST", "1") == "1"
 
+    def _inner_convs_native(self, x) -> bool:
+        """Channels-last activations are the layout of the library's own convolution kernels; a tower takes it only when
+        every convolution apart from the image-side one (the first of an encoder, the last of a decoder) runs on them.
+        Towers with other channel counts keep plain NCHW tensors, so the backend never receives channels-last tensors
+        with a handful of channels (a combination that only reduced-size test models produce)."""
+        convs = [m for m in self if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))]
+        if len(convs) < 2:
+            return False
+        inner = convs[:-1] if isinstance(convs[-1], nn.ConvTranspose2d) else convs[1:]
+        return all(_native_conv_ok(m, x) for m in inner)
+
     @staticmethod
     def _fusable(m, nxt, shape, x):
         return (isinstance(m, nn.LayerNorm) and isinstance(nxt, nn.SiLU) and x.dtype == torch.float32 and len(shape) == 4
@@ -352,7 +363,7 @@ class _Tower(nn.Sequential):
         i = 0
         if not self.fuse or not x.is_cuda:
             return super().forward(x)
-        if self.channels_last and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] >= 64:
+        if self.channels_last and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] >= 64 and self._inner_convs_native(x):
             x = x.contiguous(memory_format=torch.channels_last)
         while i < len(mods):
             m = mods[i]

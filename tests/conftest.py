@@ -11,7 +11,11 @@ if ROOT not in sys.path:
 # DRM_GUARD_ALLOC=1: every device tensor of the test process comes from the red-zone allocator in tools/guard_alloc
 # (regions of their own with canary-filled margins, bodies pre-filled with 0xFF); after each test the margins of all
 # freed and live tensors are compared with the canary and a write outside any tensor fails that test.
+# GUARD_FLUSH=1 on top of it: every tensor ends 0-15 bytes before an unmapped page, so a read or write of 16 bytes or
+# more past the end of any tensor is a memory fault at that kernel (diagnostic runs; with DRM_SYNC_CHECK=2 the last
+# "[drm] launched" line on stderr names the library launch).
 GUARD = os.environ.get("DRM_GUARD_ALLOC", "0") == "1"
+GUARD_FLUSH = GUARD and os.environ.get("GUARD_FLUSH", "0") == "1"
 _guard = None
 if GUARD:
     import ctypes

@@ -9,7 +9,8 @@ from dreamer_amd import _native as N
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(not conftest.GUARD, reason="runs under DRM_GUARD_ALLOC=1 only")
+@pytest.mark.skipif(not conftest.GUARD or conftest.GUARD_FLUSH,
+                    reason="runs under DRM_GUARD_ALLOC=1 only (and not in the flush form, where the write would fault)")
 def test_guard_allocator_reports_a_write_past_the_end():
     conftest.guard_report()
     dst = torch.zeros(10, dtype=torch.float32, device="cuda:0")       # 40 bytes

@@ -115,11 +115,11 @@ def test_channels_last_towers_match_plain_sequential(monkeypatch, which):
     torch.manual_seed(4)
     n = 70
     if which == "encoder":
-        mod = W.Encoder((3, 64, 64), base_cnn_channels=8).to(DEV).conv
+        mod = W.Encoder((3, 64, 64), base_cnn_channels=32).to(DEV).conv
         args = (torch.rand(n, 3, 64, 64, device=DEV),)
         fn = lambda: mod(*args)
     else:
-        dec = W.Decoder((3, 64, 64), base_cnn_channels=8, num_latents=8, hidden_size=64).to(DEV)
+        dec = W.Decoder((3, 64, 64), base_cnn_channels=32, num_latents=8, hidden_size=64).to(DEV)
         h = torch.randn(n, 64, device=DEV)
         z = F.one_hot(torch.randint(0, 32, (n, 8), device=DEV), 32).float()
         mod, fn = dec, (lambda: dec(h, z))

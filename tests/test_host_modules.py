@@ -160,3 +160,24 @@ def test_precision_names_resolve_to_library_codes(monkeypatch):
     assert resolve_precision("f32", 4096, 512, 512) == 0
     with pytest.raises(ValueError):
         resolve_precision("fp16", 16, 512, 512)
+
+
+def test_towers_take_channels_last_only_with_natively_convolved_channel_counts():
+    """Channels-last activations are handed out only when every convolution apart from the image-side one runs on the
+    library's own kernels; reduced models (4-32 channels) keep NCHW tensors for the backend's routines."""
+    from types import SimpleNamespace
+
+    from dreamer_amd import world_model as W
+
+    def probe(n, shape):
+        return SimpleNamespace(is_cuda=True, dtype=torch.float32, dim=lambda: 4, shape=(n,) + shape)
+
+    enc32 = W.Encoder((3, 64, 64), base_cnn_channels=32).conv
+    dec32 = W.Decoder((3, 64, 64), base_cnn_channels=32, num_latents=8, hidden_size=64).deconv
+    enc4 = W.Encoder((3, 16, 16), base_cnn_channels=4).conv
+    dec8 = W.Decoder((3, 64, 64), base_cnn_channels=8, num_latents=8, hidden_size=64).deconv
+    assert enc32._inner_convs_native(probe(1024, (3, 64, 64)))
+    assert dec32._inner_convs_native(probe(1024, (256, 4, 4)))
+    assert not enc4._inner_convs_native(probe(84, (3, 16, 16)))
+    assert not dec8._inner_convs_native(probe(70, (64, 4, 4)))
+    assert not enc32._inner_convs_native(probe(8, (3, 64, 64)))      # below the native kernels' image count

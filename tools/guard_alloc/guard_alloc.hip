@@ -9,6 +9,15 @@
 //   * when a tensor is freed (and on demand for every live one) a kernel compares the red zones with the canary:
 //     a write past the end of any tensor, by any kernel of any library, is recorded with the size of the tensor it
 //     belongs to, the side and the byte distance.
+//
+// GUARD_FLUSH=1 switches to the other form, which finds READS past the end as well: a tensor's region comes from the
+// virtual-memory interface (hipMemAddressReserve / hipMemCreate / hipMemMap) with one more granule of address space
+// reserved behind it that is never mapped, and the body ends on the region's last 16-byte boundary.  Any access of
+// 16 bytes or more past the end of any tensor is then a memory fault of the kernel that made it, whatever the order
+// of the tests (diagnostic runs only: the fault ends the process; DRM_SYNC_CHECK=2 names the library launch).  The
+// leading red zone (GUARD_RZ_MB) stays mapped and canary-checked.  A memory fault is fatal for more than the process on
+// shared machines (the node's GPU service may end the whole box): use this form only where that is acceptable, for one
+// run with a known question, never in a loop.
 // Test infrastructure only: nothing in the product path loads this file.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,6 +44,8 @@ struct Report {
 
 struct Block {
     char* base; size_t total, size; unsigned long long seq; hipEvent_t ev;
+    size_t lead;                     // bytes between base and the body (the leading red zone; flush form: varies with size)
+    hipMemGenericAllocationHandle_t handle; bool flush;
 };
 
 std::mutex g_mu;
@@ -50,6 +61,49 @@ size_t rz_bytes() {
     return v;
 }
 size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+bool flush_mode() {
+    static const bool v = [] { const char* e = std::getenv("GUARD_FLUSH"); return e != nullptr && e[0] != '0'; }();
+    return v;
+}
+size_t g_gran[MAX_DEV] = {};
+hipMemAllocationProp vm_prop(int device) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    return prop;
+}
+size_t granule(int device) {
+    if (g_gran[device] == 0) {
+        hipMemAllocationProp prop = vm_prop(device);
+        size_t g = 0;
+        if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || g == 0) g = (size_t)2 << 20;
+        g_gran[device] = g;
+    }
+    return g_gran[device];
+}
+// a mapped region of `total` bytes followed by one reserved, unmapped granule
+bool vm_region(int device, size_t total, Block* b) {
+    const size_t g = granule(device);
+    hipMemAllocationProp prop = vm_prop(device);
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, total + g, g, nullptr, 0) != hipSuccess) return false;
+    if (hipMemCreate(&b->handle, total, &prop, 0) != hipSuccess) { (void)hipMemAddressFree(va, total + g); return false; }
+    if (hipMemMap(va, total, 0, b->handle, 0) != hipSuccess) { (void)hipMemRelease(b->handle); (void)hipMemAddressFree(va, total + g); return false; }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(va, total, &acc, 1) != hipSuccess) {
+        (void)hipMemUnmap(va, total); (void)hipMemRelease(b->handle); (void)hipMemAddressFree(va, total + g); return false;
+    }
+    b->base = (char*)va; b->total = total; b->flush = true;
+    return true;
+}
+void vm_release(int device, Block& b) {
+    (void)hipMemUnmap(b.base, b.total);
+    (void)hipMemRelease(b.handle);
+    (void)hipMemAddressFree(b.base, b.total + granule(device));
+}
 
 __global__ __launch_bounds__(256) void k_fill(uint32_t* p, size_t words, uint32_t v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = v;
@@ -79,12 +133,11 @@ Report* report_of(int dev) {
 }
 
 void launch_check(const Block& b, Report* rep, hipStream_t s) {
-    const size_t rz = rz_bytes();
     const size_t body4 = up(b.size, 4);
     const uint32_t* lo = reinterpret_cast<const uint32_t*>(b.base);
-    const uint32_t* hi = reinterpret_cast<const uint32_t*>(b.base + rz + body4);
-    const size_t hi_words = (b.total - rz - body4) / 4;
-    k_check<<<dim3(256), dim3(256), 0, s>>>(lo, rz / 4, hi, hi_words, rep, b.seq, (unsigned long long)b.size);
+    const uint32_t* hi = reinterpret_cast<const uint32_t*>(b.base + b.lead + body4);
+    const size_t hi_words = (b.total - b.lead - body4) / 4;
+    k_check<<<dim3(256), dim3(256), 0, s>>>(lo, b.lead / 4, hi, hi_words, rep, b.seq, (unsigned long long)b.size);
 }
 
 }  // namespace
@@ -95,7 +148,8 @@ extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t stream) {
     (void)hipGetDevice(&prev);
     if (prev != device) (void)hipSetDevice(device);
     const size_t rz = rz_bytes();
-    const size_t total = rz + up((size_t)size, 256) + rz;
+    const bool flush = flush_mode();
+    const size_t total = flush ? up(rz + up((size_t)size, 16), granule(device)) : rz + up((size_t)size, 256) + rz;
     Block b{};
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -105,18 +159,21 @@ extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t stream) {
         ++g_mallocs;
     }
     if (b.base == nullptr) {
-        if (hipMalloc((void**)&b.base, total) != hipSuccess) { if (prev != device) (void)hipSetDevice(prev); return nullptr; }
+        const bool ok = flush ? vm_region(device, total, &b) : hipMalloc((void**)&b.base, total) == hipSuccess;
+        if (!ok) { if (prev != device) (void)hipSetDevice(prev); return nullptr; }
         b.total = total;
         (void)hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
     } else {
         (void)hipStreamWaitEvent(stream, b.ev, 0);     // the check of its previous life has finished
     }
     b.size = (size_t)size;
+    b.lead = flush ? total - up(b.size, 16) : rz;      // flush form: the body ends on the region's last 16-byte boundary
     const size_t body4 = up(b.size, 4);
-    k_fill<<<dim3(64), dim3(256), 0, stream>>>(reinterpret_cast<uint32_t*>(b.base), rz / 4, CANARY);
-    (void)hipMemsetAsync(b.base + rz, 0xFF, body4, stream);
-    k_fill<<<dim3(64), dim3(256), 0, stream>>>(reinterpret_cast<uint32_t*>(b.base + rz + body4), (total - rz - body4) / 4, CANARY);
-    void* body = b.base + rz;
+    k_fill<<<dim3(64), dim3(256), 0, stream>>>(reinterpret_cast<uint32_t*>(b.base), b.lead / 4, CANARY);
+    (void)hipMemsetAsync(b.base + b.lead, 0xFF, body4, stream);
+    if (total > b.lead + body4)
+        k_fill<<<dim3(64), dim3(256), 0, stream>>>(reinterpret_cast<uint32_t*>(b.base + b.lead + body4), (total - b.lead - body4) / 4, CANARY);
+    void* body = b.base + b.lead;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_live[body] = b;
@@ -149,7 +206,7 @@ extern "C" void guard_free(void* ptr, ssize_t /*size*/, int device, hipStream_t 
     if (!keep) {
         (void)hipStreamSynchronize(stream);
         (void)hipEventDestroy(b.ev);
-        (void)hipFree(b.base);
+        if (b.flush) vm_release(device, b); else (void)hipFree(b.base);
     }
     if (prev != device) (void)hipSetDevice(prev);
 }
@@ -180,11 +237,11 @@ extern "C" int guard_report(int device, unsigned long long* out, int reset) {
             if (reset) {
                 (void)hipMemset(rep, 0, sizeof(Report));
                 if (h.count != 0) {      // heal the live regions so that one stray write is reported once
-                    const size_t rz = rz_bytes();
                     for (auto& b : live) {
                         const size_t body4 = up(b.size, 4);
-                        k_fill<<<dim3(64), dim3(256), 0, nullptr>>>(reinterpret_cast<uint32_t*>(b.base), rz / 4, CANARY);
-                        k_fill<<<dim3(64), dim3(256), 0, nullptr>>>(reinterpret_cast<uint32_t*>(b.base + rz + body4), (b.total - rz - body4) / 4, CANARY);
+                        k_fill<<<dim3(64), dim3(256), 0, nullptr>>>(reinterpret_cast<uint32_t*>(b.base), b.lead / 4, CANARY);
+                        if (b.total > b.lead + body4)
+                            k_fill<<<dim3(64), dim3(256), 0, nullptr>>>(reinterpret_cast<uint32_t*>(b.base + b.lead + body4), (b.total - b.lead - body4) / 4, CANARY);
                     }
                     (void)hipDeviceSynchronize();
                 }
