@@ -53,19 +53,25 @@ class ReplayBuffer:
         self.idx = (self.idx + n) % self.capacity
 
     # ---- persistence (the reference keeps its buffer in memory only and saves nothing: lib/trainer.py:326-335) ----
-    def state_dict(self) -> Dict[str, torch.Tensor]:
+    def state_dict(self, stamp=None) -> Dict[str, torch.Tensor]:
         """The filled part of the ring and its write position, as host tensors only (a file written with
-        ``torch.save`` of this dict loads with ``torch.load(..., weights_only=True)``)."""
+        ``torch.save`` of this dict loads with ``torch.load(..., weights_only=True)``).  ``stamp``: integers that
+        identify the checkpoint the ring belongs to (kept under "stamp"; compared by the loader of the pair)."""
         n = len(self)
-        return {"observations": self.observations[:n].cpu(), "actions": self.actions[:n].cpu(),
-                "rewards": self.rewards[:n].cpu(), "continues": self.continues[:n].cpu(),
-                "meta": torch.tensor([self.capacity, self.idx, int(self.full), self.seq_len], dtype=torch.int64)}
+        sd = {"observations": self.observations[:n].cpu(), "actions": self.actions[:n].cpu(),
+              "rewards": self.rewards[:n].cpu(), "continues": self.continues[:n].cpu(),
+              "meta": torch.tensor([self.capacity, self.idx, int(self.full), self.seq_len], dtype=torch.int64)}
+        if stamp is not None:
+            sd["stamp"] = torch.tensor([int(v) for v in stamp], dtype=torch.int64)
+        return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
-        cap, idx, full, _ = (int(v) for v in sd["meta"])
+        cap, idx, full, seq_len = (int(v) for v in sd["meta"])
         if cap != self.capacity or tuple(sd["observations"].shape[1:]) != self.obs_shape:
             raise ValueError(f"replay file holds capacity {cap}, frames {tuple(sd['observations'].shape[1:])}; this ring has "
                              f"capacity {self.capacity}, frames {self.obs_shape}")
+        if seq_len != self.seq_len:
+            raise ValueError(f"replay file was written for sequences of {seq_len} steps; this ring samples {self.seq_len}")
         n = sd["actions"].numel()
         if n != (cap if full else idx):
             raise ValueError("replay file is inconsistent: stored rows do not match its write position")
@@ -75,11 +81,19 @@ class ReplayBuffer:
         self.continues[:n].copy_(sd["continues"])
         self.idx, self.full = idx, bool(full)
 
-    def save(self, path: str) -> None:
-        torch.save(self.state_dict(), path)
+    def save(self, path: str, stamp=None) -> None:
+        torch.save(self.state_dict(stamp), path)
 
-    def load(self, path: str) -> None:
-        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+    def load(self, path: str, expect_stamp=None) -> bool:
+        """Load a ring written by ``save``.  With ``expect_stamp`` the file is taken only when it carries that stamp
+        (a ring left behind by another checkpoint is not paired with newer counters); returns whether it was taken."""
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        if expect_stamp is not None:
+            have = [int(v) for v in sd["stamp"]] if "stamp" in sd else None
+            if have != [int(v) for v in expect_stamp]:
+                return False
+        self.load_state_dict(sd)
+        return True
 
     def draw_starts(self, batch_size: int) -> np.ndarray:
         assert len(self) >= self.seq_len, "Not enough data to sample."

@@ -406,37 +406,88 @@ def _rng_restore(snap) -> None:
         torch.cuda.set_rng_state(snap["torch_cuda"].cpu())
 
 
-def save_checkpoint(directory: str, learner: "Learner", counters: Dict[str, float], buffer: Optional[ReplayBuffer] = None) -> None:
-    """``ckpt.pth`` with the reference's six entries (lib/trainer.py:326-335) plus ``trainer_state`` (update / step
-    counters, train-ratio credit, generator states; tensors and plain numbers only), written to a temporary name and
-    moved into place; with ``buffer`` the replay ring goes to ``replay.pth`` beside it."""
+def _rank_file(directory: str, stem: str, rank: int) -> str:
+    """Per-rank file names: rank 0 keeps the plain name (a single-process run reads and writes what it always did)."""
+    return os.path.join(directory, f"{stem}.pth" if rank == 0 else f"{stem}.rank{rank}.pth")
+
+
+def _replace(tmp: str, final: str) -> None:
+    os.replace(tmp, final)
+
+
+def save_checkpoint(directory: str, learner: "Learner", counters: Dict[str, float], buffer: Optional[ReplayBuffer] = None,
+                    rank: int = 0) -> None:
+    """Rank 0: ``ckpt.pth`` with the reference's six entries (lib/trainer.py:326-335) plus ``trainer_state`` (update /
+    step counters, train-ratio credit, generator states; tensors and plain numbers only), written to a temporary name
+    and moved into place.  Every other rank of a data-parallel run writes ``rng.rank<r>.pth`` with its own generator
+    states (the ranks draw different batches and actions; models and optimisers are identical, so rank 0's copy serves
+    all).  With ``buffer`` each rank's replay ring goes to ``replay.pth`` / ``replay.rank<r>.pth``, stamped with the
+    counters of this checkpoint; without it a ring file left by an earlier checkpoint is removed, so that it cannot be
+    paired with these counters later."""
     os.makedirs(directory, exist_ok=True)
-    sd = learner.state_dicts()
-    sd["trainer_state"] = {"counters": {k: float(v) for k, v in counters.items()}, "rng": _rng_snapshot()}
-    tmp = os.path.join(directory, "ckpt.pth.tmp")
-    torch.save(sd, tmp)
-    os.replace(tmp, os.path.join(directory, "ckpt.pth"))
+    stamp = (int(counters.get("updates_done", 0)), int(counters.get("policy_steps", 0)))
+    replay = _rank_file(directory, "replay", rank)
     if buffer is not None:
-        tmp = os.path.join(directory, "replay.pth.tmp")
-        buffer.save(tmp)
-        os.replace(tmp, os.path.join(directory, "replay.pth"))
+        tmp = replay + ".tmp"
+        buffer.save(tmp, stamp=stamp)
+        _replace(tmp, replay)       # the ring first: a crash before the checkpoint lands leaves a ring whose stamp no
+    elif os.path.exists(replay):    # checkpoint carries, and the loader skips it
+        os.remove(replay)
+    if rank == 0:
+        sd = learner.state_dicts()
+        sd["trainer_state"] = {"counters": {k: float(v) for k, v in counters.items()}, "rng": _rng_snapshot()}
+        tmp = os.path.join(directory, "ckpt.pth.tmp")
+        torch.save(sd, tmp)
+        _replace(tmp, os.path.join(directory, "ckpt.pth"))
+    else:
+        tmp = _rank_file(directory, "rng", rank) + ".tmp"
+        torch.save({"rng": _rng_snapshot(), "stamp": torch.tensor(stamp, dtype=torch.int64)}, tmp)
+        _replace(tmp, _rank_file(directory, "rng", rank))
 
 
-def load_checkpoint(path: str, learner: "Learner", buffer: Optional[ReplayBuffer] = None) -> Dict[str, float]:
-    """Restore a learner (and, when ``replay.pth`` lies beside the checkpoint, the replay ring) from ``path``
-    (a directory or the ``ckpt.pth`` file).  Files are read with ``weights_only=True``: nothing in them is executed.
-    A checkpoint written by the reference (no ``trainer_state``) restores models and optimisers and returns {}."""
+def load_checkpoint(path: str, learner: "Learner", buffer: Optional[ReplayBuffer] = None, rank: int = 0,
+                    verbose: bool = False) -> Dict[str, float]:
+    """Restore a learner (and, when this rank's stamped replay file lies beside the checkpoint, the replay ring) from
+    ``path`` (a directory or the ``ckpt.pth`` file).  Files are read with ``weights_only=True``: nothing in them is
+    executed.  A checkpoint written by the reference (no ``trainer_state``) restores models and optimisers and
+    returns {}.  Generator states: rank 0 takes the checkpoint's; another rank takes its own ``rng.rank<r>.pth`` when
+    that file carries the checkpoint's stamp, and otherwise reseeds from the checkpoint's state offset by its rank --
+    never rank 0's state itself, which would make every rank draw the same batches and actions."""
     ckpt = os.path.join(path, "ckpt.pth") if os.path.isdir(path) else path
+    directory = os.path.dirname(ckpt)
     sd = torch.load(ckpt, map_location=learner.cfg.device, weights_only=True)
     learner.load_state_dicts(sd)
-    replay = os.path.join(os.path.dirname(ckpt), "replay.pth")
-    if buffer is not None and os.path.exists(replay):
-        buffer.load(replay)
     extra = sd.get("trainer_state")
+    counters = dict(extra["counters"]) if extra else {}
+    stamp = (int(counters.get("updates_done", 0)), int(counters.get("policy_steps", 0))) if extra else None
+    replay = _rank_file(directory, "replay", rank)
+    if buffer is not None and os.path.exists(replay):
+        taken = buffer.load(replay, expect_stamp=stamp)
+        if not taken and verbose:
+            print(f"{replay} belongs to another checkpoint (stamp differs from {stamp}): replay ring not restored")
     if not extra:
         return {}
+    if rank == 0:
+        _rng_restore(extra["rng"])
+        return counters
+    own = _rank_file(directory, "rng", rank)
+    if os.path.exists(own):
+        mine = torch.load(own, map_location="cpu", weights_only=True)
+        if [int(v) for v in mine["stamp"]] == list(stamp):
+            _rng_restore(mine["rng"])
+            return counters
     _rng_restore(extra["rng"])
-    return dict(extra["counters"])
+    _reseed_for_rank(rank)
+    return counters
+
+
+def _reseed_for_rank(rank: int) -> None:
+    """Host and device generators moved to a stream of this rank's own, derived from their current state."""
+    if rank == 0:
+        return
+    base = int(np.random.randint(0, 2 ** 31 - 1))
+    np.random.seed((base + 7919 * rank) % (2 ** 31 - 1))
+    torch.manual_seed((base + 104729 * rank) % (2 ** 63 - 1))
 
 
 def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True, resume: Optional[str] = None,
@@ -470,7 +521,7 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True, resu
     policy = ActingPolicy(wm, actor, cfg.device, obs_shape)
     current_obs = None
     if resume is not None:
-        c = load_checkpoint(resume, learner, buffer)
+        c = load_checkpoint(resume, learner, buffer, rank=D.rank(), verbose=verbose)
         updates_done, policy_steps = int(c.get("updates_done", 0)), int(c.get("policy_steps", 0))
         update_credit = float(c.get("update_credit", 0.0))
         policy.reset()    # the environment starts a new episode; the recurrent state does too
@@ -513,12 +564,14 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True, resu
             update_credit -= credits_per_update
             updates_done += 1
             update_counter += 1
-            if is_main and (updates_done - 1) % cfg.save_interval == 0 and updates_done > 1 and cfg.checkpoint_dir is not None:
+            if (updates_done - 1) % cfg.save_interval == 0 and updates_done > 1 and cfg.checkpoint_dir is not None:
                 # after update number `updates_done - 1` (the reference's save point, lib/trainer.py:326-335), with
-                # the counters as they stand once that update is accounted for
+                # the counters as they stand once that update is accounted for; rank 0 writes the models, every rank
+                # its own generator states and (with save_replay) its own ring
                 save_checkpoint(cfg.checkpoint_dir, learner, {"updates_done": updates_done, "policy_steps": policy_steps,
                                                               "update_credit": update_credit},
-                                buffer if save_replay else None)
-                print(f"Saved model checkpoint to {cfg.checkpoint_dir}")
+                                buffer if save_replay else None, rank=D.rank())
+                if is_main:
+                    print(f"Saved model checkpoint to {cfg.checkpoint_dir}")
     env.close()
     return learner

@@ -95,3 +95,89 @@ def test_lib_alias_package_matches_reference_imports():
     from lib.critic import Critic  # noqa: F401
     from lib.utils import symexp, make_env  # noqa: F401
     assert C2 is Config and t2 is train
+
+
+def test_replay_file_of_another_checkpoint_is_not_paired_with_newer_counters(tmp_path):
+    """The ring file carries the counters of the checkpoint it was written with; a checkpoint saved later without the
+    ring removes it, a stamp that differs is skipped, and a ring written for another sequence length is refused."""
+    import pytest
+
+    from dreamer_amd.replay_buffer import ReplayBuffer
+    from dreamer_amd.trainer import Learner, load_checkpoint, save_checkpoint
+    try:
+        cfg = _tiny_cfg(1)
+        learner = Learner(cfg, (3, 16, 16), 3)
+        ring = ReplayBuffer(16, (3, 16, 16), 6, cfg.device)
+        for i in range(9):
+            ring.store(np.full((3, 16, 16), i, np.uint8), i % 3, float(i), True)
+        save_checkpoint(str(tmp_path), learner, {"updates_done": 5, "policy_steps": 9, "update_credit": 0.0}, ring)
+        fresh = ReplayBuffer(16, (3, 16, 16), 6, cfg.device)
+        load_checkpoint(str(tmp_path), learner, fresh)
+        assert len(fresh) == 9
+        # a ring stamped for other counters (as a crash between the two renames leaves it) is skipped
+        ring.save(str(tmp_path / "replay.pth"), stamp=(4, 8))
+        fresh = ReplayBuffer(16, (3, 16, 16), 6, cfg.device)
+        load_checkpoint(str(tmp_path), learner, fresh)
+        assert len(fresh) == 0
+        # saving without the ring removes the file of the earlier checkpoint
+        save_checkpoint(str(tmp_path), learner, {"updates_done": 6, "policy_steps": 10, "update_credit": 0.0}, None)
+        assert not (tmp_path / "replay.pth").exists()
+        # sequence length is part of the file
+        ring.save(str(tmp_path / "other.pth"))
+        with pytest.raises(ValueError, match="sequences of 6"):
+            ReplayBuffer(16, (3, 16, 16), 5, cfg.device).load(str(tmp_path / "other.pth"))
+    finally:
+        Config.num_latents, Config.classes_per_latent = 32, 32
+
+
+def _resume_worker(rank, world, port, directory, out):
+    import os
+
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        torch.manual_seed(0); np.random.seed(0)
+        cfg = _tiny_cfg(14)
+        cfg.checkpoint_dir, cfg.save_interval = directory, 4
+        train(cfg, env=SyntheticPixelEnv(16, n_actions=3, episode_len=5, seed=rank), verbose=False, save_replay=True)
+        # the resumed ranks: generator states and rings are their own, not rank 0's
+        torch.manual_seed(123); np.random.seed(123)        # whatever state the new process starts with
+        from dreamer_amd.replay_buffer import ReplayBuffer
+        from dreamer_amd.trainer import Learner, load_checkpoint
+        learner = Learner(cfg, (3, 16, 16), 3)
+        ring = ReplayBuffer(cfg.replay_capacity, (3, 16, 16), cfg.batch_length, cfg.device)
+        load_checkpoint(directory, learner, ring, rank=rank)
+        starts = ring.draw_starts(8)
+        torch.save({"starts": torch.from_numpy(starts), "obs": ring.observations[:len(ring)].clone(),
+                    "torch_draw": torch.rand(4)}, os.path.join(out, f"r{rank}.pt"))
+        # without its own generator file a rank still ends up on a stream of its own
+        if rank == 1:
+            os.remove(os.path.join(directory, "rng.rank1.pth"))
+        dist.barrier()
+        load_checkpoint(directory, learner, ring, rank=rank)
+        torch.save({"starts": torch.from_numpy(ring.draw_starts(8)), "torch_draw": torch.rand(4)},
+                   os.path.join(out, f"r{rank}_reseeded.pt"))
+    finally:
+        Config.num_latents, Config.classes_per_latent = 32, 32
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_resume_under_data_parallelism_keeps_the_ranks_apart(tmp_path):
+    """Two ranks (gloo) train, checkpoint and resume: each rank comes back with its own generator states and its own
+    replay ring, so the ranks keep drawing different batches (restoring rank 0's states on every rank would average
+    N copies of one gradient)."""
+    import torch.multiprocessing as mp
+
+    from test_dp_gloo import _free_port
+    ck, out = tmp_path / "ck", tmp_path / "out"
+    ck.mkdir(); out.mkdir()
+    mp.spawn(_resume_worker, args=(2, _free_port(), str(ck), str(out)), nprocs=2, join=True)
+    for f in ("ckpt.pth", "replay.pth", "replay.rank1.pth"):
+        assert (ck / f).exists(), f
+    a, b = torch.load(out / "r0.pt", weights_only=True), torch.load(out / "r1.pt", weights_only=True)
+    assert not torch.equal(a["starts"], b["starts"]) and not torch.equal(a["torch_draw"], b["torch_draw"])
+    assert not torch.equal(a["obs"], b["obs"])              # each rank's own environment frames
+    a2, b2 = torch.load(out / "r0_reseeded.pt", weights_only=True), torch.load(out / "r1_reseeded.pt", weights_only=True)
+    assert torch.equal(a2["starts"], a["starts"])           # rank 0 resumes the same stream every time
+    assert not torch.equal(b2["starts"], a2["starts"]) and not torch.equal(b2["torch_draw"], a2["torch_draw"])
