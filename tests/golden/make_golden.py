@@ -116,6 +116,9 @@ DIMS = {
     # kernel-compatible reduced dims: 32 classes per latent, widths multiple of 32
     "small": dict(obs_shape=(3, 16, 16), A=4, L=8, K=32, D=64, M=64, C=4, B=4, H=5, T=6),
     "default": dict(obs_shape=(3, 64, 64), A=6, L=32, K=32, D=512, M=512, C=32, B=16, H=15, T=3),
+    # the scaled model: recurrent width 4096 with the full 32 x 32 latent (hidden width of the MLPs 512), 16 sequences;
+    # short horizon / sequence so that the stored outputs stay small
+    "c5": dict(obs_shape=(3, 64, 64), A=6, L=32, K=32, D=4096, M=512, C=32, B=16, H=3, T=3),
 }
 
 
@@ -259,7 +262,9 @@ def golden_observe(tag, out_dir, salt, B=None, T=None, name=None, compact=False,
                dyn=info["dyn_loss"].detach().numpy(), rep=info["rep_loss"].detach().numpy(),
                zidx=torch.stack(trace["idx"], 1).numpy().astype(np.uint8),
                h_last=info["state"].h.detach().numpy(), z_margin=np.float64(margin))
-    if compact:
+    if compact and T < 8:
+        out.update(h=torch.stack(trace["h"], 1).numpy(), post_last=post[:, -1].numpy(), prior_last=trace["prior"][-1].numpy())
+    elif compact:
         out.update(h_every8=torch.stack(trace["h"], 1)[:, 7::8].numpy(), post_last=post[:, -1].numpy(),
                    prior_last=trace["prior"][-1].numpy())
     else:
@@ -364,8 +369,11 @@ def golden_state_keys(out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only-c5", action="store_true", help="write the scaled-model fixtures only")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.only_c5:
+        return golden_c5(args.out)
     golden_state_keys(args.out)
     golden_pointwise(args.out)
     golden_replay(args.out)
@@ -382,6 +390,18 @@ def main():
     for name, T, salt in (("observe_full", 64, 31), ("observe_t50", 50, 41)):
         while not golden_observe("default", args.out, salt=salt, B=16, T=T, name=name, compact=True, min_margin=1.0e-4):
             salt += 1
+    golden_c5(args.out)
+
+
+def golden_c5(out_dir):
+    """The scaled model (recurrent width 4096, full 32 x 32 latent) at 16 sequences: a 3-step imagination block and the
+    world-model loss + backward over 16 x 3 frames, outputs only."""
+    salt = 51
+    while not golden_imagine("c5", out_dir, salt=salt, min_margin=1.5e-4):
+        salt += 1
+    salt = 61
+    while not golden_observe("c5", out_dir, salt=salt, B=16, T=3, name="observe_c5", compact=True, min_margin=1.0e-4):
+        salt += 1
 
 
 if __name__ == "__main__":

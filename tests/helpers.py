@@ -16,6 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DIMS = {
     "small": dict(obs_shape=(3, 16, 16), A=4, L=8, K=32, D=64, M=64, C=4, B=4, H=5, T=6),
     "default": dict(obs_shape=(3, 64, 64), A=6, L=32, K=32, D=512, M=512, C=32, B=16, H=15, T=3),
+    "c5": dict(obs_shape=(3, 64, 64), A=6, L=32, K=32, D=4096, M=512, C=32, B=16, H=3, T=3),
 }
 
 

@@ -63,7 +63,7 @@ def test_replay_errors():
         buf.draw_starts(2)
 
 
-@pytest.mark.parametrize("tag", ["small", "default"])
+@pytest.mark.parametrize("tag", ["small", "default", "c5"])
 def test_imagine_block(tag):
     g = load(f"imagine_{tag}.npz")
     d, salt = DIMS[tag], int(g["salt"])
@@ -138,6 +138,30 @@ def test_observe_full_size_batches(name):
     assert rel_err(info["h_last"].detach(), g["h_last"]) < TOL
     assert rel_err(info["post_logits"].detach()[:, -1], g["post_last"]) < TOL
     assert rel_err(info["prior_logits"].detach().reshape(B, T, d["L"], d["K"])[:, -1], g["prior_last"]) < TOL
+    assert rel_err(total.detach(), g["total"]) < TOL
+    for key in ("pred", "dyn", "rep"):
+        assert rel_err(info[key + "_loss"].detach(), g[key]) < TOL, key
+    total.backward()
+    for name_, ref in zip(g["grad_names"], g["grad_norms"]):
+        grad = w[str(name_)].grad
+        if ref < 0:
+            assert grad is None or float(grad.abs().max()) == 0.0, name_
+        else:
+            assert abs(float(grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-3), (name_, float(grad.double().norm()), ref)
+
+
+def test_observe_scaled_model():
+    """The scaled model (recurrent width 4096, 32 x 32 latent) over 16 x 3 frames: the oracle's loss terms, draws, states
+    and gradient norms equal the reference's."""
+    g = load("observe_c5.npz")
+    d, salt, B, T = DIMS["c5"], int(g["salt"]), int(g["B"]), int(g["T"])
+    wm, _, _ = build_models(d, salt)
+    w = {k: v.requires_grad_(v.is_floating_point()) for k, v in weights_of(wm).items()}
+    obs, actions, rewards, continues, noise = observe_inputs(d, salt, B, T)
+    total, info = O.wm_loss(w, obs.float() / 255.0, actions, rewards, continues, noise["init"], noise["reset"], noise["z"])
+    assert np.array_equal(info["idx"].numpy().astype(np.uint8), g["zidx"])
+    assert rel_err(info["h"].detach(), g["h"]) < TOL
+    assert rel_err(info["post_logits"].detach()[:, -1], g["post_last"]) < TOL
     assert rel_err(total.detach(), g["total"]) < TOL
     for key in ("pred", "dyn", "rep"):
         assert rel_err(info[key + "_loss"].detach(), g[key]) < TOL, key
