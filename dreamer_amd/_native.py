@@ -124,6 +124,10 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "drm_convt_k4s2_forward": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_convt_k4s2_input_grad": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]),
+    "drm_conv_img_down": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_conv_img_up": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_conv_img_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int32] * 4),
+    "drm_conv_img_wgrad": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_down": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_up": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int32] * 4),
@@ -341,6 +345,74 @@ def convt_k4s2_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     check(lib().drm_convt_k4s2_forward(x.data_ptr(), weight.data_ptr(), ptr(bias), y.data_ptr(), n, cin, cout, h, w,
                                        stream_ptr(x.device)), "drm_convt_k4s2_forward")
     return y
+
+
+def conv_img_ok(cs: int, cimg: int, up: bool = False) -> bool:
+    """Whether the image-side kernels take a layer with `cimg` image channels and `cs` feature channels."""
+    return 1 <= cimg <= 4 and cs % 32 == 0 and 32 <= cs <= (128 if up else 512)
+
+
+def _img_operands(small, big, weight, what):
+    """Shapes of the image-side layer: small (N, Cs, H, W) logical in channels-last memory, big (N, Cimg, 2H, 2W) NCHW."""
+    n, cs, h, w = small.shape
+    cimg = big.shape[1]
+    if tuple(big.shape) != (n, cimg, 2 * h, 2 * w) or (weight is not None and tuple(weight.shape) != (cs, cimg, 4, 4)):
+        raise NativeError(f"{what}: feature map {tuple(small.shape)}, image {tuple(big.shape)}"
+                          + (f" and weight {tuple(weight.shape)}" if weight is not None else "") + " do not fit one k4 s2 p1 layer")
+    if not conv_img_ok(cs, cimg):
+        raise NativeError(f"{what}: {cimg} image channels / {cs} feature channels are outside the kernels' range")
+    return n, cs, cimg, h, w
+
+
+def conv_img_down(big: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """conv2d(big, weight, stride 2, padding 1) without bias for an image with at most 4 channels: big (N, Cimg, 2H, 2W)
+    contiguous, weight (Cs, Cimg, 4, 4); the result (N, Cs, H, W) is in channels-last memory."""
+    require_cuda(big, weight)
+    _dense(big, torch.float32, "big"); _dense(weight, torch.float32, "weight")
+    n, cimg, h2, w2 = big.shape
+    cs = weight.shape[0]
+    if h2 % 2 or w2 % 2:
+        raise NativeError(f"conv_img_down: image {tuple(big.shape)} needs even height and width")
+    out = torch.empty((n, cs, h2 // 2, w2 // 2), dtype=torch.float32, device=big.device, memory_format=torch.channels_last)
+    _img_operands(out, big, weight, "conv_img_down")
+    check(lib().drm_conv_img_down(big.data_ptr(), weight.data_ptr(), out.data_ptr(), n, cs, cimg, h2 // 2, w2 // 2,
+                                  stream_ptr(big.device)), "drm_conv_img_down")
+    return out
+
+
+def conv_img_up(small: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """conv_transpose2d(small, weight, stride 2, padding 1) + bias for at most 4 output channels: small (N, Cs, H, W) in
+    channels-last memory, weight (Cs, Cimg, 4, 4); the result (N, Cimg, 2H, 2W) is contiguous."""
+    require_cuda(small, weight)
+    small = _cl4(small, "small")
+    _dense(weight, torch.float32, "weight")
+    n, cs, h, w = small.shape
+    cimg = weight.shape[1]
+    if bias is not None:
+        _dense(bias, torch.float32, "bias")
+        _require_bytes(bias, 4 * cimg, "bias")
+    out = torch.empty((n, cimg, 2 * h, 2 * w), dtype=torch.float32, device=small.device)
+    _img_operands(small, out, weight, "conv_img_up")
+    if not conv_img_ok(cs, cimg, up=True):
+        raise NativeError(f"conv_img_up: {cs} feature channels are outside the kernel's range")
+    check(lib().drm_conv_img_up(small.data_ptr(), weight.data_ptr(), ptr(bias), out.data_ptr(), n, cs, cimg, h, w,
+                                stream_ptr(small.device)), "drm_conv_img_up")
+    return out
+
+
+def conv_img_wgrad(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
+    """Weight gradient (Cs, Cimg, 4, 4) of the image-side layer: sum over images and positions of small[n, cs, i, j] *
+    big[n, cimg, 2i - 1 + ky, 2j - 1 + kx]; small in channels-last memory, big contiguous."""
+    require_cuda(small, big)
+    small = _cl4(small, "small")
+    _dense(big, torch.float32, "big")
+    n, cs, cimg, h, w = _img_operands(small, big, None, "conv_img_wgrad")
+    need = lib().drm_conv_img_wgrad_workspace_bytes(n, cs, cimg, h, w)
+    ws = torch.empty(need // 4 + 4, dtype=torch.float32, device=small.device)
+    gw = torch.empty((cs, cimg, 4, 4), dtype=torch.float32, device=small.device)
+    check(lib().drm_conv_img_wgrad(small.data_ptr(), big.data_ptr(), gw.data_ptr(), ws.data_ptr(), ws.numel() * 4, n, cs, cimg,
+                                   h, w, stream_ptr(small.device)), "drm_conv_img_wgrad")
+    return gw
 
 
 def convt_k4s2_input_grad(grad_y: torch.Tensor, weight: torch.Tensor, channels_last: bool) -> torch.Tensor:

@@ -201,11 +201,16 @@ class _ConvBiasFn(torch.autograd.Function):
         ctx.conf = (transposed, stride, padding)
         ctx.direct = (transposed and weight.shape[1] <= 4 and tuple(weight.shape[2:]) == (4, 4) and tuple(stride) == (2, 2)
                       and tuple(padding) == (1, 1) and x.dtype == torch.float32 and _ConvBiasFn.native_convt)
-        if ctx.direct and x.is_contiguous():
-            # few output channels: a stream, served by the library's direct kernel (bias included); an input in
-            # channels-last memory takes the backend's routine, which reads that layout faster
+        ctx.img = False
+        if ctx.direct:
+            # few output channels: a stream, served by the library's direct kernels (bias included) in either memory
+            # format of the input
             from . import _native as N
-            return N.convt_k4s2_forward(x, weight.contiguous(), bias)
+            ctx.img = N._is_channels_last(x) and not x.is_contiguous() and N.conv_img_ok(weight.shape[0], weight.shape[1], up=True)
+            if ctx.img:
+                return N.conv_img_up(x, weight.contiguous(), bias)
+            if x.is_contiguous():
+                return N.convt_k4s2_forward(x, weight.contiguous(), bias)
         if transposed:
             return F.conv_transpose2d(x, weight, bias, stride=stride, padding=padding)
         return F.conv2d(x, weight, bias, stride=stride, padding=padding)
@@ -220,8 +225,11 @@ class _ConvBiasFn(torch.autograd.Function):
             # (a reduction over all pixels) from the backend's routine
             from . import _native as N
             gx = N.convt_k4s2_input_grad(g, weight.contiguous(), N._is_channels_last(x)) if ctx.needs_input_grad[0] else None
-            _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1], transposed,
-                                                           [0, 0], 1, [False, True, False])
+            if ctx.img:
+                gw = N.conv_img_wgrad(x, g)       # channels-last input: the reduction over all pixels on the library's kernel
+            else:
+                _, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1],
+                                                               transposed, [0, 0], 1, [False, True, False])
         else:
             gx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, list(stride), list(padding), [1, 1], transposed,
                                                             [0, 0], 1, [ctx.needs_input_grad[0], True, False])
@@ -304,6 +312,45 @@ class _Conv4s2Fn(torch.autograd.Function):
         return gx, gw, None
 
 
+class _ConvImgDownFn(torch.autograd.Function):
+    """nn.Conv2d(Cimg <= 4 -> Cs, kernel 4, stride 2, padding 1, no bias) on an image: the first encoder layer on the
+    library's kernels (forward and weight gradient); the result is in channels-last memory."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from . import _native as N
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        return N.conv_img_down(x, weight.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _native as N
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            gw = N.conv_img_wgrad(g, x)
+        if ctx.needs_input_grad[0]:        # an image that requires a gradient: not a training path; the backend's routine
+            gx = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        return gx, gw
+
+
+def _image_conv_ok(mod, x) -> bool:
+    """The first encoder layer (an image with at most 4 channels in, a multiple of 32 channels out) on the library's
+    image-side kernels."""
+    if not (isinstance(mod, nn.Conv2d) and not isinstance(mod, nn.ConvTranspose2d)):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] >= NATIVE_CONV_MIN_IMAGES
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+        return False
+    if not (tuple(mod.kernel_size) == (4, 4) and tuple(mod.stride) == (2, 2) and tuple(mod.padding) == (1, 1)
+            and tuple(mod.dilation) == (1, 1) and mod.groups == 1 and mod.padding_mode == "zeros"):
+        return False
+    from . import _native as N
+    return N.conv_img_ok(mod.out_channels, mod.in_channels)
+
+
 # the towers' stride-2 4x4 layers run on the library's kernels from this many images on (DRM_NO_NATIVE_CONV=1: never)
 NATIVE_CONV_MIN_IMAGES = 10 ** 9 if os.environ.get("DRM_NO_NATIVE_CONV", "0") == "1" else int(os.environ.get("DRM_NATIVE_CONV_MIN_IMAGES", "16"))
 
@@ -322,7 +369,9 @@ def _native_conv_ok(mod, x) -> bool:
     return all(N.conv4s2_ok(cs, cb, m) for m in ("down", "up", "wgrad"))
 
 
-def _conv_no_bias(mod, x):
+def _conv_no_bias(mod, x, image_conv: bool = False):
+    if image_conv and _image_conv_ok(mod, x):
+        return _ConvImgDownFn.apply(x, mod.weight)
     if _native_conv_ok(mod, x):
         return _Conv4s2Fn.apply(x, mod.weight, isinstance(mod, nn.ConvTranspose2d))
     if isinstance(mod, nn.ConvTranspose2d):
@@ -363,7 +412,9 @@ class _Tower(nn.Sequential):
         i = 0
         if not self.fuse or not x.is_cuda:
             return super().forward(x)
-        if self.channels_last and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] >= 64 and self._inner_convs_native(x):
+        cl = self.channels_last and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] >= 64 and self._inner_convs_native(x)
+        # an encoder's image goes to the image-side kernel as it is (NCHW in, channels-last out)
+        if cl and not (len(mods) > 0 and _image_conv_ok(mods[0], x)):
             x = x.contiguous(memory_format=torch.channels_last)
         while i < len(mods):
             m = mods[i]
@@ -373,7 +424,7 @@ class _Tower(nn.Sequential):
                 shape = (x.shape[0],) + tuple(ln.normalized_shape)
                 hw = shape[2] * shape[3] if len(shape) == 4 else 0
                 if self._fusable(ln, mods[i + 2], shape, x) and hw % 4 == 0 and shape[1] == m.out_channels:
-                    y = _conv_no_bias(m, x)
+                    y = _conv_no_bias(m, x, image_conv=cl and i == 0)
                     if shape[1] % 4 != 0:
                         y = y.contiguous()     # the channels-last kernels take channel counts that are multiples of 4
                     x = _LayerNormSiLUFn.apply(y, ln.weight, ln.bias, ln.eps, m.bias)

@@ -147,6 +147,25 @@ int drm_convt_k4s2_forward(const float* x, const float* weight, const float* bia
 int drm_convt_k4s2_input_grad(const float* grad_y, const float* weight, float* grad_x, int64_t N, int32_t Cin, int32_t Cout,
                               int32_t H, int32_t W, int32_t channels_last, drm_stream_t stream);
 
+/* The image-side ends of the conv towers: a kernel-4 stride-2 padding-1 layer between an image `big` (N, Cimg <= 4, 2H, 2W;
+ * contiguous NCHW) and a feature map `small` (N, H, W, Cs) in channels-last memory (Cs a multiple of 32), with `weight`
+ * (Cs, Cimg, 4, 4) -- the layout of both nn.Conv2d(Cimg, Cs).weight and nn.ConvTranspose2d(Cs, Cimg).weight.
+ *   drm_conv_img_down : small = conv2d(big, weight), no bias      (first encoder layer forward, lib/world_model.py:94-97,
+ *                       :131; its bias is added by the LayerNorm kernel that follows)
+ *   drm_conv_img_up   : big = conv_transpose2d(small, weight) + bias (bias (Cimg) or NULL; last decoder layer forward,
+ *                       lib/world_model.py:298-302, :318; Cs <= 128)
+ *   drm_conv_img_wgrad: grad_weight[cs][cimg][ky][kx] = sum_{n,i,j} small[n,i,j,cs] * big[n,cimg,2i-1+ky,2j-1+kx] -- the
+ *                       weight gradient autograd forms for either layer (small = the conv's output gradient and big its
+ *                       input, or small = the transposed conv's input and big its output gradient).  `workspace`: device
+ *                       memory of drm_conv_img_wgrad_workspace_bytes(...) bytes (partial sums, added in a fixed order). */
+int drm_conv_img_down(const float* big, const float* weight, float* small_out, int64_t N, int32_t Cs, int32_t Cimg, int32_t H,
+                      int32_t W, drm_stream_t stream);
+int drm_conv_img_up(const float* small_in, const float* weight, const float* bias, float* big_out, int64_t N, int32_t Cs,
+                    int32_t Cimg, int32_t H, int32_t W, drm_stream_t stream);
+size_t drm_conv_img_wgrad_workspace_bytes(int64_t N, int32_t Cs, int32_t Cimg, int32_t H, int32_t W);
+int drm_conv_img_wgrad(const float* small_in, const float* big, float* grad_weight, void* workspace, size_t workspace_bytes,
+                       int64_t N, int32_t Cs, int32_t Cimg, int32_t H, int32_t W, drm_stream_t stream);
+
 /* ---- stride-2 4x4 convolutions of the towers as implicit fp32 MFMA products, channels-last activations ----------
  * nn.Conv2d(cb -> cs, kernel 4, stride 2, padding 1) (lib/world_model.py:94-108) and nn.ConvTranspose2d(cs -> cb, kernel 4,
  * stride 2, padding 1) (lib/world_model.py:290-302), without bias (the bias is applied by the fused LayerNorm + SiLU that
