@@ -349,7 +349,7 @@ def convt_k4s2_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
 
 def conv_img_ok(cs: int, cimg: int, up: bool = False) -> bool:
     """Whether the image-side kernels take a layer with `cimg` image channels and `cs` feature channels."""
-    return 1 <= cimg <= 4 and cs % 32 == 0 and 32 <= cs <= (128 if up else 512)
+    return 1 <= cimg <= 4 and cs % 32 == 0 and 32 <= cs <= 512
 
 
 def _img_operands(small, big, weight, what):

@@ -153,7 +153,7 @@ int drm_convt_k4s2_input_grad(const float* grad_y, const float* weight, float* g
  *   drm_conv_img_down : small = conv2d(big, weight), no bias      (first encoder layer forward, lib/world_model.py:94-97,
  *                       :131; its bias is added by the LayerNorm kernel that follows)
  *   drm_conv_img_up   : big = conv_transpose2d(small, weight) + bias (bias (Cimg) or NULL; last decoder layer forward,
- *                       lib/world_model.py:298-302, :318; Cs <= 128)
+ *                       lib/world_model.py:298-302, :318)
  *   drm_conv_img_wgrad: grad_weight[cs][cimg][ky][kx] = sum_{n,i,j} small[n,i,j,cs] * big[n,cimg,2i-1+ky,2j-1+kx] -- the
  *                       weight gradient autograd forms for either layer (small = the conv's output gradient and big its
  *                       input, or small = the transposed conv's input and big its output gradient).  `workspace`: device

@@ -36,7 +36,7 @@ def test_down_matches_conv2d(n, cs, cimg, h, w):
     assert _rel(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize("n,cs,cimg,h,w", [s for s in SHAPES if s[1] <= 128])
+@pytest.mark.parametrize("n,cs,cimg,h,w", SHAPES + [(2, 64, 3, 9, 33), (1, 32, 3, 17, 70)])
 def test_up_matches_conv_transpose2d(n, cs, cimg, h, w):
     _, small, weight, bias = _case(n, cs, cimg, h, w)
     ref = F.conv_transpose2d(small.double(), weight.double(), bias.double(), stride=2, padding=1)
@@ -86,5 +86,5 @@ def test_shapes_outside_the_kernels_range_are_refused():
     with pytest.raises(N.NativeError):
         N.conv_img_down(torch.zeros(2, 5, 8, 8, device=DEV), torch.zeros(32, 5, 4, 4, device=DEV))   # 5 image channels
     with pytest.raises(N.NativeError):
-        N.conv_img_up(torch.zeros(2, 256, 4, 4, device=DEV).contiguous(memory_format=torch.channels_last),
-                      torch.zeros(256, 3, 4, 4, device=DEV), None)         # more weights than the LDS image holds
+        N.conv_img_up(torch.zeros(2, 48, 4, 4, device=DEV).contiguous(memory_format=torch.channels_last),
+                      torch.zeros(48, 3, 4, 4, device=DEV), None)          # 48 feature channels

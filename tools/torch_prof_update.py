@@ -22,4 +22,4 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for _ in range(3):
         L.update(buf.sample(16, want_f32=True))
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=50, max_shapes_column_width=70))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("ROWS", "40")), max_name_column_width=50, max_shapes_column_width=70))
