@@ -145,6 +145,7 @@ def measure_train(device, world, rank, steps, warmup, fence):
     torch.manual_seed(0)
     torch.backends.cudnn.benchmark = True   # as the reference's main.py:11 sets it (MIOpen picks its conv kernels by search)
     learner = Learner(cfg, (3, 64, 64), 6)
+    learner.make_stream_current()      # as dreamer_amd.trainer.train does: sampling, updates and acting on one stream
     with torch.no_grad():
         for head in (learner.world_model.rew.head, learner.world_model.cont.head, learner.actor.head, learner.critic.head):
             torch.nn.init.normal_(head.weight, std=0.05)

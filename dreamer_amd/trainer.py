@@ -82,6 +82,11 @@ class _GraphedUpdate:
         self.g_loss = self.g_step = None
         self.loss_out = None
 
+    def matches(self, inputs) -> bool:
+        """Whether ``inputs`` have the shapes and types the recording was made with (always true before it is made)."""
+        return self.static is None or (len(self.static) == len(inputs) and all(
+            d.shape == s.shape and d.dtype == s.dtype for d, s in zip(self.static, inputs)))
+
     def run(self, *inputs: torch.Tensor) -> torch.Tensor:
         if self.g_loss is None:
             self._capture(inputs)
@@ -261,10 +266,16 @@ class Learner:
         self.graph_updates = on_gpu and os.environ.get("DRM_NO_UPDATE_GRAPHS", "0") != "1"
         self.eager_updates = 0
         self._wm_graph = _GraphedUpdate(None, self.g_wm, cfg.world_model_grad_clip, self.optim_world_model)
-        # opt-in (DRM_WM_GRAPH=1): the world-model loss + backward recorded too.  It replays correctly (same losses as
-        # the eager update) but not faster: launching this graph of ~450 nodes takes the host 7.8 ms, against 9-10 ms
-        # for issuing the same launches eagerly, and the update comes out at 11.6 ms against 10.8 ms
-        self.wm_graph = self.graph_updates and os.environ.get("DRM_WM_GRAPH", "0") == "1"
+        # Every update runs on one stream of the learner's own (DRM_ONE_STREAM=0: on the caller's): the recordings below
+        # are then made on the stream the eager warm-up updates ran on, autograd's gradient-accumulation nodes belong to
+        # it, and each recorded update is a single chain of nodes that the host launches in ~0.2 ms (recorded from the
+        # default stream's context the same update becomes a fork-join graph that takes the host 7.8 ms to launch).
+        self._stream = (torch.cuda.Stream(device=dev) if self.graph_updates and os.environ.get("DRM_ONE_STREAM", "1") == "1"
+                        else None)
+        # The world-model loss + backward recorded too (DRM_WM_GRAPH=0: eager): ~800 launches whose enqueueing costs the
+        # host ~10 ms per update when issued one by one; replayed, the host is free for the environment loop and the
+        # update takes its device time.
+        self.wm_graph = self.graph_updates and self._stream is not None and os.environ.get("DRM_WM_GRAPH", "1") == "1"
         self._wm_aux = None
 
         def _wm_loss(obs, actions, rewards, continues):
@@ -280,21 +291,54 @@ class Learner:
             lambda h, z, act, ret, val, scale: self.actor.loss_with_scale(WorldModelState(h=h, z=z), act, ret, val, scale),
             self.g_actor, cfg.actor_critic_grad_clip, self.optim_actor)
 
+    def make_stream_current(self) -> None:
+        """Make the learner's stream the calling thread's current stream (ordered after what the previous current
+        stream has queued).  A loop that samples, updates and acts on this one stream saves the two cross-stream
+        hand-overs per update that ``update`` otherwise needs (measured: 10.9 against 11.7 ms per update)."""
+        if self._stream is not None and torch.cuda.current_stream() != self._stream:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            torch.cuda.set_stream(self._stream)
+
     def update(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """One training update (lib/trainer.py:162-247).  On the GPU the work is issued on the learner's own stream,
+        ordered after what the caller's stream has queued so far; the caller's stream waits for it before going on
+        (no hand-over when the caller already works on that stream, see ``make_stream_current``)."""
+        if self._stream is None:
+            return self._update(batch)
+        cur = torch.cuda.current_stream()
+        if cur == self._stream:
+            return self._update(batch)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            out = self._update(batch)
+        cur.wait_stream(self._stream)
+        return out
+
+    def _update(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         cfg = self.cfg
         obs = batch.get("observations_f32")
         if obs is None:
             obs = batch["observations"].float() / 255.0
         # ---- world model ----
-        if self.wm_graph and self.eager_updates >= 3:
-            wm_loss = self._wm_full.run(obs, batch["actions"], batch["rewards"], batch["continues"]).detach().clone()
-            wm_info = self._wm_aux
-        else:
+        wm_recorded = False
+        wm_inputs = (obs, batch["actions"], batch["rewards"], batch["continues"])
+        if self.wm_graph and self.eager_updates >= 3 and self._wm_full.matches(wm_inputs):
+            try:
+                wm_loss = self._wm_full.run(*wm_inputs).detach().clone()
+                wm_info = self._wm_aux
+                wm_recorded = True
+            except RuntimeError as exc:
+                if self._wm_full.g_step is not None:      # a replay failed: not something eager execution would fix
+                    raise
+                print(f"[dreamer_amd] recording the world-model update failed ({exc}); it stays eager", flush=True)
+                self.wm_graph = False
+                self._wm_full.g_loss = self._wm_full.g_step = None
+        if not wm_recorded:
             wm_loss, wm_info = self.world_model.loss(obs, batch["actions"], batch["rewards"], batch["continues"])
             self.g_wm.zero()
             wm_loss.backward()
             self.g_wm.sync()
-        if self.wm_graph and self.eager_updates >= 3:
+        if wm_recorded:
             pass                                    # clip + step were part of the recorded update
         elif isinstance(self.optim_world_model, FlatAdam):
             self.optim_world_model.step()          # two launches: nothing to gain from a recorded graph
@@ -505,6 +549,7 @@ def train(cfg: Config, summary_writer=None, env=None, verbose: bool = True, resu
     if is_main and verbose:
         print(f"Observation shape: {obs_shape}, Action size: {act_size}")
     learner = Learner(cfg, obs_shape, act_size)
+    learner.make_stream_current()      # sampling, updates and acting share one stream from here on
     wm, actor = learner.world_model, learner.actor
     if is_main and verbose:
         count = lambda m: sum(p.numel() for p in m.parameters())

@@ -19,10 +19,8 @@ buf = ReplayBuffer(cap, (3, 64, 64), cfg.batch_length, dev)
 buf.store_many(rng.integers(0, 256, size=(cap, 3, 64, 64), dtype=np.uint8), rng.integers(0, 6, size=cap),
                rng.standard_normal(cap).astype(np.float32), rng.random(cap) > 0.01)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-if os.environ.get("DRM_ONE_STREAM", "0") == "1":      # every update, eager or recorded, on one stream of our own
-    own = torch.cuda.Stream()
-    own.wait_stream(torch.cuda.current_stream())
-    torch.cuda.set_stream(own)
+if os.environ.get("PROBE_ON_LEARNER_STREAM", "0") == "1" and learner._stream is not None:   # the caller works on the learner's stream
+    learner.make_stream_current()
 for i in range(n):
     out = learner.update(buf.sample(cfg.batch_size, want_f32=True))
     torch.cuda.synchronize()
