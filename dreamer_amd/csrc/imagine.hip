@@ -549,7 +549,7 @@ struct GatherJob {
     const float* base; int64_t ldb;     // row stride of base (0: one vector for every row)
     float* out; int64_t ldo;
     int N, cw;                          // columns, columns per slice (multiple of 4)
-    float* stats = nullptr;             // or: (rows, slices) x (sum, sum of squares) of the out values of the slice
+    float* stats = nullptr;             // or: (rows, slices) x (sum, sum of squared deviations from the slice mean) of the out values
 };
 struct SampleGatherArgs {
     SampleRowsArgs s;                   // logits == nullptr: no draw, z = forced
@@ -645,15 +645,24 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
             J.out[(int64_t)b * J.ldo + n] = a;
         }
         if (J.stats != nullptr) {           // uniform: every thread takes part in the sums
-            float st[2] = {a, a * a};
-            all_sum64<2>(st);
+            // the slice's sum, then its sum of squared deviations from the slice mean (two rounds over the four waves)
+            const bool mine = tid < J.cw && n < J.N;
+            float st[1] = {a};
+            all_sum64<1>(st);
             __syncthreads();                // s_red[gi] has been read by every thread of this pass
-            if ((tid & 63) == 0) { s_red[gi][(tid >> 6) * 2] = st[0]; s_red[gi][(tid >> 6) * 2 + 1] = st[1]; }
+            if ((tid & 63) == 0) s_red[gi][tid >> 6] = st[0];
+            __syncthreads();
+            const float sm = (s_red[gi][0] + s_red[gi][1]) + (s_red[gi][2] + s_red[gi][3]);
+            const int cnt = min(J.cw, J.N - slice * J.cw);
+            const float dv = mine ? a - sm / (float)max(cnt, 1) : 0.f;
+            float sq[1] = {dv * dv};
+            all_sum64<1>(sq);
+            __syncthreads();
+            if ((tid & 63) == 0) s_red[gi][4 + (tid >> 6)] = sq[0];
             __syncthreads();
             if (tid == 0)
                 *reinterpret_cast<float2*>(J.stats + ((int64_t)b * gridDim.x + slice) * 2) =
-                    make_float2((s_red[gi][0] + s_red[gi][2]) + (s_red[gi][4] + s_red[gi][6]),
-                                (s_red[gi][1] + s_red[gi][3]) + (s_red[gi][5] + s_red[gi][7]));
+                    make_float2(sm, (s_red[gi][4] + s_red[gi][5]) + (s_red[gi][6] + s_red[gi][7]));
         }
     }
 }
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
 // rows per output row from L2 costs more than the product over h itself; here a workgroup owns a slab of 32 columns of
 // one table, copies it into LDS once (L*32 rows x 128 bytes <= 128 KB) and walks its share of the rows, so the gather
 // runs at LDS speed and global memory sees one read-modify-write of the output.  Optionally leaves the row statistics
-// (sum, sum of squares over the slab's columns: one part per slab) for a consumer that normalises while loading.
+// (sum, sum of squared deviations from the slab's mean: one part per slab) for a consumer that normalises while loading.
 // ------------------------------------------------------------------------------------------------
 struct TableAddJob {
     const float* tab; int64_t ldt;
@@ -741,9 +750,11 @@ __global__ __launch_bounds__(1024) void k_table_add(const TableAddArgs P) {
         }
         const float4 y = make_float4(cur.x + a.x, cur.y + a.y, cur.z + a.z, cur.w + a.w);
         *reinterpret_cast<float4*>(J.out + (int64_t)r * J.ldo + n0 + c4) = y;
-        if (J.stats != nullptr) {       // uniform per workgroup
+        if (J.stats != nullptr) {       // uniform per workgroup: the slab's sum and sum of squared deviations from its mean
             const float sm = group_sum<8>((y.x + y.y) + (y.z + y.w));
-            const float sq = group_sum<8>(fmaf(y.x, y.x, y.y * y.y) + fmaf(y.z, y.z, y.w * y.w));
+            const float mp = sm * (1.0f / 32.0f);
+            const float d0 = y.x - mp, d1 = y.y - mp, d2 = y.z - mp, d3 = y.w - mp;
+            const float sq = group_sum<8>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             if ((tid & 7) == 0)
                 *reinterpret_cast<float2*>(J.stats + ((int64_t)r * parts + slab) * 2) = make_float2(sm, sq);
         }
@@ -830,8 +841,10 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         DRM_REQUIRE(q.X && q.W && q.Y && q.K >= 32 && q.K % 32 == 0 && q.N >= 1, DRM_EINVAL, "bad big problem");
         DRM_REQUIRE(aligned16(q.X) && aligned16(q.W) && q.ldx % 4 == 0 && q.ldw % 4 == 0, DRM_EINVAL, "misaligned operand");
         DRM_REQUIRE(!q.add && !q.rowscale, DRM_EINVAL, "large-row GEMM: no add / row-scale epilogue");
-        DRM_REQUIRE(!q.ln_g || (precision != 1 && q.ln_b && q.stats_in && q.parts_in >= 1 && q.parts_in <= 16), DRM_EINVAL,
-                    "large-row GEMM: LayerNorm on load needs the fp32 or the split form and the row statistics (1..16 parts)");
+        DRM_REQUIRE(!q.ln_g || (precision != 1 && q.ln_b && q.stats_in && q.parts_in >= 1 && q.parts_in <= 16 && q.part_w_in >= 1 &&
+                                (int64_t)q.parts_in * q.part_w_in >= q.K && (int64_t)(q.parts_in - 1) * q.part_w_in < q.K),
+                    DRM_EINVAL, "large-row GEMM: LayerNorm on load needs the fp32 or the split form and the row statistics "
+                    "(1..16 slices whose width covers the row)");
         DRM_REQUIRE(!q.stats_out || precision != 1, DRM_EINVAL, "large-row GEMM: row statistics come from the fp32 and split forms only");
         DRM_REQUIRE(!q.tab || zidx, DRM_EINVAL, "gather table without indices");
         BigProblem& p = L.p[i];
@@ -840,8 +853,11 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         p.ln_g = q.ln_g; p.ln_b = q.ln_b; p.stats_in = q.stats_in; p.parts_in = q.parts_in; p.stats_out = q.stats_out;
         // slices per row of the statistics: 32 columns per accumulator column block when stored from the accumulators,
         // one per column tile through LDS (problems with a table)
-        p.parts_out = q.stats_out ? (q.tab || precision == 2 ? (q.N + bn - 1) / bn : (q.N + bn / 2 - 1) / (bn / 2)) : 0;
+        const int pw_out = q.tab || precision == 2 ? bn : bn / 2;
+        p.parts_out = q.stats_out ? (q.N + pw_out - 1) / pw_out : 0;
+        p.pw_in = q.part_w_in;
         specs[i].parts_out = p.parts_out;
+        specs[i].part_w_out = q.stats_out ? pw_out : 0;
         tiles += (q.N + bn - 1) / bn;
         const double n = q.N, k = q.K, m = M;
         fl += 2.0 * m * n * k + (q.tab ? (double)latents * m * n : 0.0);
@@ -1150,7 +1166,8 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
     };
     float* st_a[2] = {fused ? ws + wl.st_a[0] : nullptr, fused ? ws + wl.st_a[1] : nullptr};
     float* st_d[2] = {fused ? ws + wl.st_d[0] : nullptr, fused ? ws + wl.st_d[1] : nullptr};
-    int parts_a[2] = {0, 0}, parts_d[2] = {0, 0};
+    int parts_a[2] = {0, 0}, parts_d[2] = {0, 0};     // slices per row of the statistics in st_a / st_d ...
+    int pw_a[2] = {0, 0}, pw_d[2] = {0, 0};           // ... and their width in columns
     if (few || fused || few_wide) {
         // ---- step-wise path.  Few rows: every layer is cut into ~256 workgroups; the draw of z and the one-hot
         // tables it selects (actor layer 1, GRU input) share one launch
@@ -1180,7 +1197,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                     a.zidx = draw ? io->zidx_out + (size_t)t * L : io->zidx0; a.ldz = draw ? (int64_t)H * L : L;
                     a.j[0] = TableAddJob{pack + pl.actor_zT, M, ws + wl.a1h, M, ws + wl.a_pre[0], M, st_a[0], M, 0};
                     a.j[1] = TableAddJob{pack + pl.lin_zT, D, w->lin_b, 0, ws + wl.xz, D, nullptr, D, M / 32};
-                    parts_a[0] = M / 32;
+                    parts_a[0] = M / 32; pw_a[0] = 32;
                     const int slabs = M / 32 + D / 32;
                     int split = cu_count() / slabs > 0 ? cu_count() / slabs : 1;   // one workgroup per CU (128 KB of LDS each): a single round
                     if (split > (B + 127) / 128) split = (B + 127) / 128;
@@ -1213,7 +1230,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 a.ng = 2;
                 a.g[0] = GatherJob{pack + pl.actor_zT, M, ws + wl.a1h, M, ws + wl.a_pre[0], M, M, cw};
                 a.g[0].stats = st_a[0];       // the consumer of a_pre[0] (actor layer 2) normalises on load
-                parts_a[0] = slices;
+                parts_a[0] = slices; pw_a[0] = cw;
                 a.g[1] = GatherJob{pack + pl.lin_zT, D, w->lin_b, 0, ws + wl.xz, D, D, cw};
             }
             ProfScope prof(PC_SAMPLE, s, (draw ? 40.0 * B * LK : 0.0) + (gather ? (double)B * L * (M + D) : 0.0),
@@ -1243,10 +1260,10 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 ProblemSpec p[2] = {{ws + wl.a_pre[(i - 1) & 1], M, w->actor.ln_g[i - 1], w->actor.ln_b[i - 1], w->actor.w[i], M,
                                      w->actor.b[i], nullptr, 0, ws + wl.a_pre[i & 1], M, M, M},
                                     giz};
-                p[0].stats_in = st_a[(i - 1) & 1]; p[0].parts_in = parts_a[(i - 1) & 1];
+                p[0].stats_in = st_a[(i - 1) & 1]; p[0].parts_in = parts_a[(i - 1) & 1]; p[0].part_w_in = pw_a[(i - 1) & 1];
                 p[0].stats_out = i < last_a ? st_a[i & 1] : nullptr;      // the last layer's consumer normalises by itself
                 if (int rc = lin(p, i == 1 ? 2 : 1)) return rc;
-                parts_a[i & 1] = p[0].parts_out;
+                parts_a[i & 1] = p[0].parts_out; pw_a[i & 1] = p[0].part_w_out;
             }
             float* h_new = io->h_out + (size_t)t * D;
             {
@@ -1277,19 +1294,20 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                     {h_new, (int64_t)H * D, nullptr, nullptr, w->actor.w[0], S, w->actor.b[0], nullptr, 0, ws + wl.a1h, M, M, D}};
                 p[0].stats_out = st_d[0];
                 if (int rc = lin(p, more ? 3 : 1)) return rc;
-                parts_d[0] = p[0].parts_out;
+                parts_d[0] = p[0].parts_out; pw_d[0] = p[0].part_w_out;
             }
             for (int i = 1; i <= last_d; ++i) {
                 ProblemSpec p{ws + wl.d_pre[(i - 1) & 1], M, w->dyn.ln_g[i - 1], w->dyn.ln_b[i - 1], w->dyn.w[i], M, w->dyn.b[i],
                               nullptr, 0, ws + wl.d_pre[i & 1], M, M, M};
-                p.stats_in = st_d[(i - 1) & 1]; p.parts_in = parts_d[(i - 1) & 1]; p.stats_out = st_d[i & 1];
+                p.stats_in = st_d[(i - 1) & 1]; p.parts_in = parts_d[(i - 1) & 1]; p.part_w_in = pw_d[(i - 1) & 1];
+                p.stats_out = st_d[i & 1];
                 if (int rc = lin(&p, 1)) return rc;
-                parts_d[i & 1] = p.parts_out;
+                parts_d[i & 1] = p.parts_out; pw_d[i & 1] = p.part_w_out;
             }
             {
                 ProblemSpec p{ws + wl.d_pre[last_d & 1], M, w->dyn.ln_g[last_d], w->dyn.ln_b[last_d], w->dyn.head_w, M,
                               w->dyn.head_b, nullptr, 0, ws + wl.logits, LK, LK, M};
-                p.stats_in = st_d[last_d & 1]; p.parts_in = parts_d[last_d & 1];
+                p.stats_in = st_d[last_d & 1]; p.parts_in = parts_d[last_d & 1]; p.part_w_in = pw_d[last_d & 1];
                 if (int rc = lin(&p, 1)) return rc;
             }
             if (int rc = sample_gather(t, true, t + 1 < H)) return rc;
@@ -1408,7 +1426,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
     int depth_max = 0;
     for (int i = 0; i < 3; ++i) depth_max = heads[i]->n_layers > depth_max ? heads[i]->n_layers : depth_max;
     float* st_h[3][2];
-    int parts_h[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    int parts_h[3][2] = {{0, 0}, {0, 0}, {0, 0}}, pw_h[3][2] = {{0, 0}, {0, 0}, {0, 0}};
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) st_h[i][j] = fused ? ws + wl.st_h[i][j] : nullptr;
     // many rows of a default-width model: the one-hot part of the first layers is added by a kernel of its own
     const bool table_add = big && !wide && L <= TABLE_ADD_MAX_L && rows >= BIG_MIN_ROWS && std::getenv("DRM_NO_TABLE_ADD") == nullptr;
@@ -1432,7 +1450,10 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
             } else {
                 continue;
             }
-            if (dep > 0) { p[np].stats_in = st_h[i][(dep - 1) & 1]; p[np].parts_in = parts_h[i][(dep - 1) & 1]; }
+            if (dep > 0) {
+                p[np].stats_in = st_h[i][(dep - 1) & 1]; p[np].parts_in = parts_h[i][(dep - 1) & 1];
+                p[np].part_w_in = pw_h[i][(dep - 1) & 1];
+            }
             if (dep < m.n_layers && feeds_product && !(dep == 0 && table_add)) p[np].stats_out = st_h[i][dep & 1];
             who[np++] = i;
         }
@@ -1440,7 +1461,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
         if (fused) {
             if (int rc = launch_big(p, np, rows, io->zidx_out, L, L, d.K, s, prec)) return rc;
             for (int q = 0; q < np; ++q)
-                if (p[q].stats_out) parts_h[who[q]][dep & 1] = p[q].parts_out;
+                if (p[q].stats_out) { parts_h[who[q]][dep & 1] = p[q].parts_out; pw_h[who[q]][dep & 1] = p[q].part_w_out; }
         } else {
             for (int q = 0; q < np; ++q) { p[q].stats_in = nullptr; p[q].parts_in = 0; p[q].stats_out = nullptr; }
             if (int rc = run_linear(p, np, rows, io->zidx_out, L, L, d.K, big, act, M, s, prec)) return rc;
@@ -1454,7 +1475,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 const bool want_stats = fused && (1 < heads[i]->n_layers || i == 2);
                 a.j[q] = TableAddJob{pack + tabs[i], M, ws + wl.head[i][0], M, ws + wl.head[i][0], M,
                                      want_stats ? st_h[i][0] : nullptr, M, q * (M / 32)};
-                if (want_stats) parts_h[i][0] = M / 32;
+                if (want_stats) { parts_h[i][0] = M / 32; pw_h[i][0] = 32; }
             }
             const int slabs = np * (M / 32);
             int split = cu_count() / slabs > 0 ? cu_count() / slabs : 1;   // one workgroup per CU (128 KB of LDS each): a single round

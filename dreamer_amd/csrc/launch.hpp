@@ -15,11 +15,13 @@ struct ProblemSpec {
     float* Y; int64_t ldy; int N, K;
     const float* add = nullptr; int64_t ldadd = 0;          // Y += add[m][n]
     const float* rowscale = nullptr; int64_t ldrs = 0;      // Y *= rowscale[m]
-    // large-row fp32 launches only: partial row sums (sum, sum of squares) per slice of the row.  stats_in: those of
-    // the X rows, which LayerNorm (ln_g / ln_b) needs; stats_out: where to leave those of the Y rows (launch_big
-    // fills parts_out with the number of slices per row it wrote)
+    // large-row fp32 launches only: per slice of the row (sum, sum of squared deviations from the slice's mean).
+    // stats_in: those of the X rows, which LayerNorm (ln_g / ln_b) needs, parts_in slices of part_w_in columns;
+    // stats_out: where to leave those of the Y rows (launch_big fills parts_out / part_w_out with the number of slices
+    // per row it wrote and their width)
     const float* stats_in = nullptr; int parts_in = 0;
     float* stats_out = nullptr; int parts_out = 0;
+    int part_w_in = 0, part_w_out = 0;
 };
 
 static inline int check_problem(const ProblemSpec& s) {

@@ -27,12 +27,16 @@ struct BigProblem {
     int N, K;
     int tile_begin;                  // first blockIdx.x (column tile) of this problem
     // fp32 form only.  LayerNorm + SiLU of the X rows on their way into LDS (the consumer normalises), with the row
-    // statistics taken from partial sums the producer of X left behind: stats_in[row][part] = (sum, sum of squares)
-    // over a slice of the row, parts_in <= 16 slices.  stats_out: the same for the Y rows this problem writes
-    // (slices of 32 NT columns when stored from the accumulators, of 64 NT columns through LDS).
+    // statistics taken from what the producer of X left behind: stats_in[row][part] = (sum, sum of squared deviations
+    // from the slice's own mean) over a slice of the row, parts_in <= 16 slices of pw_in columns; the consumer merges the
+    // slices with the pairwise update of Chan et al. (mean from the sums, M2 = sum of the slices' M2 plus
+    // n_p (mean_p - mean)^2), so a row whose mean is large against its spread loses no digits to a subtraction of two
+    // large numbers.  stats_out: the same for the Y rows this problem writes (slices of 32 NT columns when stored from
+    // the accumulators, of 64 NT columns through LDS).
     const float* ln_g = nullptr; const float* ln_b = nullptr;
     const float* stats_in = nullptr; int parts_in = 0;
     float* stats_out = nullptr; int parts_out = 0;
+    int pw_in = 0;                   // columns per slice of stats_in (the last slice of a row may be shorter)
     const uint16_t* Ws = nullptr;    // W as bf16 images [planes][N][K] made by k_split_planes (split form: 3 planes; bf16 form: 1), or nullptr
 };
 
@@ -127,10 +131,13 @@ __device__ __forceinline__ void big_epilogue(const BigLaunch& L, const BigProble
                 if (n + 3 < P.N) out[3] = y.w;
             }
         }
-        if (P.stats_out != nullptr) {       // partial row sums over this tile's columns (uniform branch)
-            const float v0 = live ? y.x : 0.f, v1 = n + 1 < P.N ? y.y : 0.f, v2 = n + 2 < P.N ? y.z : 0.f, v3 = n + 3 < P.N ? y.w : 0.f;
+        if (P.stats_out != nullptr) {       // sum and centred sum of squares over this tile's columns (uniform branch)
+            const bool l1 = n + 1 < P.N, l2 = n + 2 < P.N, l3 = n + 3 < P.N;
+            const float v0 = live ? y.x : 0.f, v1 = l1 ? y.y : 0.f, v2 = l2 ? y.z : 0.f, v3 = l3 ? y.w : 0.f;
             const float sm = group_sum<TPR>((v0 + v1) + (v2 + v3));
-            const float sq = group_sum<TPR>((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3));
+            const float mp = sm / (float)min(BN, P.N - n0);
+            const float d0 = live ? y.x - mp : 0.f, d1 = l1 ? y.y - mp : 0.f, d2 = l2 ? y.z - mp : 0.f, d3 = l3 ? y.w - mp : 0.f;
+            const float sq = group_sum<TPR>((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             if (tid % TPR == 0)
                 *reinterpret_cast<float2*>(P.stats_out + ((int64_t)m * P.parts_out + n0 / BN) * 2) = make_float2(sm, sq);
         }
@@ -208,16 +215,19 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
         GP = LN ? Q.ln_g + skq : XA[0]; BP = LN ? Q.ln_b + skq : XA[0];                               \
         /* row statistics: the 8 threads of a staging row fetch two parts each (no branch around the loads) */ \
         const float* st_ = LN ? Q.stats_in : Q.X;                                                     \
-        const int np_ = LN ? Q.parts_in : 1;                                                          \
+        const int np_ = LN ? Q.parts_in : 1, pw_ = LN ? Q.pw_in : 1;                                  \
         if (LNT) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                      \
             const int64_t row_ = LN ? (int64_t)min(M0 + srow + 32 * i, L.M - 1) : 0;                  \
             const int p0_ = (tid & 7) * 2, p1_ = p0_ + 1;                                             \
             const float2 a_ = *reinterpret_cast<const float2*>(st_ + (row_ * np_ + min(p0_, np_ - 1)) * 2);  \
             const float2 b_ = *reinterpret_cast<const float2*>(st_ + (row_ * np_ + min(p1_, np_ - 1)) * 2);  \
             const float sm_ = group_sum<8>((p0_ < np_ ? a_.x : 0.f) + (p1_ < np_ ? b_.x : 0.f));      \
-            const float sq_ = group_sum<8>((p0_ < np_ ? a_.y : 0.f) + (p1_ < np_ ? b_.y : 0.f));      \
             const float mean_ = sm_ / (float)Q.K;                                                     \
-            MU[i] = mean_; RS[i] = 1.0f / sqrtf(fmaxf(sq_ / (float)Q.K - mean_ * mean_, 0.f) + LN_EPS);  \
+            /* slices merged as (count, mean, M2) triples: M2 = sum M2_p + n_p (mean_p - mean)^2 */   \
+            const float n0_ = (float)min(pw_, Q.K - p0_ * pw_), n1_ = (float)min(pw_, Q.K - p1_ * pw_);  \
+            const float d0_ = a_.x / n0_ - mean_, d1_ = b_.x / n1_ - mean_;                           \
+            const float m2_ = group_sum<8>((p0_ < np_ ? a_.y + n0_ * d0_ * d0_ : 0.f) + (p1_ < np_ ? b_.y + n1_ * d1_ * d1_ : 0.f)); \
+            MU[i] = mean_; RS[i] = 1.0f / sqrtf(fmaxf(m2_ / (float)Q.K, 0.f) + LN_EPS);               \
         }                                                                                             \
     }
     BIG_TILE(tbase + tj, pi, m0, n0, nk, xa, wb, ln, mu, rs, gp, bp)
@@ -352,32 +362,48 @@ __global__ __launch_bounds__(256) void k_linear_big(const BigLaunch L) {
                 }
             }
             if (LNT && P.stats_out != nullptr) {
-                // partial row sums over the wave's 32 NT columns: 16 rows per lane half; per quantity one 32-value
-                // halving butterfly over the wave (each half contributes zeros in the other half's slots)
+                // per row, over the wave's 32 NT columns: the sum, then the sum of squared deviations from that slice
+                // mean.  16 rows per lane half; per quantity one 32-value halving butterfly over the wave (each half
+                // contributes zeros in the other half's slots), after which lane l holds the total of value number
+                // bit-reverse5(l & 31); the slice means travel back to the lanes that hold the rows' entries by ds_bpermute
                 int idx = 0;
 #pragma unroll
                 for (int j = 0; j < 5; ++j) idx |= ((lane >> j) & 1) << (4 - j);
                 const int half = idx >> 4, irow = idx & 15;
                 const int m = m0 + wm * 32 + (irow & 3) + 8 * (irow >> 2) + 4 * half;
                 const int part = (n0 + wn * 32 * NT) / (32 * NT);
+                const int cnt = min(32 * NT, P.N - (n0 + wn * 32 * NT));       // columns of this slice inside the matrix
+                bool colv[NT];
 #pragma unroll
-                for (int which = 0; which < 2; ++which) {
-                    float v[32];
+                for (int j = 0; j < NT; ++j) colv[j] = (n0 + wn * 32 * NT + 32 * j + li) < P.N;
+                float v[32];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float t = 0.f;
+                for (int i = 0; i < 16; ++i) {
+                    float t = 0.f;
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) {
-                            const float y = (n0 + wn * 32 * NT + 32 * j + li) < P.N ? acc[j][i] : 0.f;
-                            t += which == 0 ? y : y * y;
-                        }
-                        v[i] = lh == 0 ? t : 0.f;
-                        v[16 + i] = lh == 1 ? t : 0.f;
-                    }
-                    const float tot = halving_sum32_big(v, lane);
-                    if (lane < 32 && m < L.M && part < P.parts_out)
-                        P.stats_out[((int64_t)m * P.parts_out + part) * 2 + which] = tot;
+                    for (int j = 0; j < NT; ++j) t += colv[j] ? acc[j][i] : 0.f;
+                    v[i] = lh == 0 ? t : 0.f;
+                    v[16 + i] = lh == 1 ? t : 0.f;
                 }
+                const float tot_sum = halving_sum32_big(v, lane);
+                const float mean_l = tot_sum / (float)max(cnt, 1);            // of value number bit-reverse5(lane & 31)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    // value number lh * 16 + i lives in lane bit-reverse5(lh * 16 + i) = (bit-reverse4(i) << 1) | lh
+                    const int br4 = ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+                    const float mean_i = __shfl(mean_l, (br4 << 1) | lh, 64);
+                    float t = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const float d = colv[j] ? acc[j][i] - mean_i : 0.f;
+                        t += d * d;
+                    }
+                    v[i] = lh == 0 ? t : 0.f;
+                    v[16 + i] = lh == 1 ? t : 0.f;
+                }
+                const float tot_m2 = halving_sum32_big(v, lane);
+                if (lane < 32 && m < L.M && part < P.parts_out)
+                    *reinterpret_cast<float2*>(P.stats_out + ((int64_t)m * P.parts_out + part) * 2) = make_float2(tot_sum, tot_m2);
             }
         } else {
             // through LDS (16-byte table-row reads and stores); the operand stages are overwritten, so such a tile is
@@ -609,7 +635,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     const float* ep = ln ? P.ln_b + skq : xa[0];
     if (LNT) {
         const float* st = ln ? P.stats_in : P.X;
-        const int np = ln ? P.parts_in : 1;
+        const int np = ln ? P.parts_in : 1, pw = ln ? P.pw_in : 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t row = ln ? (int64_t)min(m0 + srow + 32 * i, L.M - 1) : 0;
@@ -617,9 +643,12 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
             const float2 a = *reinterpret_cast<const float2*>(st + (row * np + min(p0, np - 1)) * 2);
             const float2 b = *reinterpret_cast<const float2*>(st + (row * np + min(p1, np - 1)) * 2);
             const float sm = group_sum<8>((p0 < np ? a.x : 0.f) + (p1 < np ? b.x : 0.f));
-            const float sq = group_sum<8>((p0 < np ? a.y : 0.f) + (p1 < np ? b.y : 0.f));
             const float mean = sm / (float)K;
-            mu[i] = mean; rsd[i] = 1.0f / sqrtf(fmaxf(sq / (float)K - mean * mean, 0.f) + LN_EPS);
+            // slices merged as (count, mean, M2) triples: M2 = sum M2_p + n_p (mean_p - mean)^2
+            const float c0 = (float)min(pw, K - p0 * pw), c1 = (float)min(pw, K - p1 * pw);
+            const float d0 = a.x / c0 - mean, d1 = b.x / c1 - mean;
+            const float m2 = group_sum<8>((p0 < np ? a.y + c0 * d0 * d0 : 0.f) + (p1 < np ? b.y + c1 * d1 * d1 : 0.f));
+            mu[i] = mean; rsd[i] = 1.0f / sqrtf(fmaxf(m2 / (float)K, 0.f) + LN_EPS);
         }
     }
     // loads are unconditional (past the end they re-read the last step)

@@ -202,6 +202,45 @@ def test_split_products_meet_the_fp32_tolerance(B, H, D, M, L):
     assert differs   # the split kernels really ran (same values to rounding, not the same bits)
 
 
+@pytest.mark.parametrize("precision", ["f32_mfma", "f32_split"])
+@pytest.mark.parametrize("M", [128, 160])
+def test_layernorm_on_load_with_shifted_preactivations(precision, M):
+    """Rows whose mean is large against their spread (pre-activations around 10 with a standard deviation of ~0.3, as a
+    trained bias can produce): the row statistics the large-row kernels hand from layer to layer are per-slice sums and
+    centred sums of squares merged pairwise, so the normalisation keeps the rollout's 1e-5 tolerance (a one-pass
+    E[x^2] - mean^2 loses ~1e-4 of the variance here, ten times the tolerance).  M = 160: slices of unequal width."""
+    d = dict(DIMS["small"], D=96, M=M, L=6, A=5)
+    salt, B, H = 1300 + M, 300, 2
+    wm, actor, critic = build_models(d, salt)
+    with torch.no_grad():
+        for mod in (wm.dyn.mlp[0], wm.dyn.mlp[3], actor.mlp[0], critic.mlp[0], wm.rew.mlp[0], wm.rew.mlp[3], wm.cont.mlp[0]):
+            mod.weight.mul_(0.3)
+            mod.bias.add_(10.0)
+    ww, wa, wc = weights_of(wm), weights_of(actor), weights_of(critic)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    dbl = lambda w: {k: (v.double() if v.is_floating_point() else v) for k, v in w.items()}
+    with torch.no_grad():
+        ref = O.imagine_block(ww, wa, wc, h0, z0, ea, ez, 0.997, 0.95)
+        ref_zidx = ref["z"].argmax(-1).to(torch.uint8)
+        # the same trajectory in fp64: what both fp32 evaluations approximate.  With pre-activations of 10 +- 0.3 the
+        # rounding of the fp32 inputs of a LayerNorm alone is ~3e-6 of its output, so the fp32 oracle itself is up to
+        # ~3e-5 away from the fp64 values here; the device path is held to the same distance (1e-5, or twice the
+        # oracle's own where that is larger)
+        truth = O.imagine_block(dbl(ww), dbl(wa), dbl(wc), h0.double(), z0.double(), ea.double(), ez.double(), 0.997, 0.95,
+                                forced_actions=ref["actions"], forced_zidx=ref_zidx)
+    out = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, precision=precision,
+                  noise={"a": ea.to(DEV), "z": ez.to(DEV)}, forced_actions=ref["actions"].to(DEV), forced_zidx=ref_zidx.to(DEV),
+                  want_prior_logits=True)
+    torch.cuda.synchronize()
+    for key in ("h", "rewards", "conts", "values", "v_last", "lam_returns", "actor_logp", "prior_logits"):
+        own = rel_err(ref[key], truth[key])
+        got = rel_err(out[key].cpu(), truth[key])
+        assert got < max(TOL, 2.0 * own), (key, got, own)
+
+
 def _check_rows_against_oracle(wm, actor, critic, h0, z0, ea, ez, got, drew=True):
     """A few rows of a device rollout against the oracle, unconditionally: the oracle is led along the device's own
     trajectory (its actions and latent classes forced), so states, heads and returns must agree to the tolerance
