@@ -1669,7 +1669,9 @@ extern "C" int drm_imagine_block_noalloc_f32(const drm_imagine_weights* w, const
     drm_imagine_io local = *io;
     local.workspace = ws;
     local.workspace_bytes = STATIC_SCRATCH_BYTES;
-    return imagine_enqueue(w, &local, stream);
+    // one chain of launches on the caller's stream, whatever the number of trajectories: the side-by-side chains of
+    // drm_imagine_block_f32 create streams and events on a thread's first call and need a workspace per chain
+    return imagine_enqueue_part(w, &local, stream, local.B);
 }
 
 #ifdef DRM_STAMPS

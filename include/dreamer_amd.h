@@ -346,7 +346,10 @@ int drm_graph_cache_clear(void);
  *     DRM_IMAGINE_NOALLOC_MAX_WORKSPACE bytes inside the library (each GPU the library runs on holds its own
  *     copy until the process ends).  A call whose drm_imagine_workspace_bytes(dims, B, H) exceeds that is
  *     rejected with DRM_ENOTSUP (at the default widths, H = 15: up to 72 trajectories);
- *   - io->use_graph must be 0 and per-kernel timing must be off (both create runtime objects);
+ *   - io->use_graph must be 0 and per-kernel timing must be off (both create runtime objects); the call is always one
+ *     chain of launches on the caller's stream (the side-by-side chains of drm_imagine_block_f32 at many trajectories
+ *     create streams and events), and with recurrent widths beyond 512 and a reduced precision the bf16 weight images
+ *     of the call live in the same array (inside the size that is checked);
  *   - it calls no hipMalloc / hipFree or any other allocating routine; the array's device address is looked up
  *     once per device on the first call made with that device current;
  *   - every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two

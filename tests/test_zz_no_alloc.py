@@ -51,3 +51,17 @@ def test_noalloc_entry_point_rejects_what_does_not_fit():
     got = _run(eng, d, salt, 3, 2, noalloc=True)
     for k in ref:
         assert torch.equal(ref[k], got[k]), k
+
+
+def test_noalloc_entry_point_runs_one_chain_at_many_trajectories():
+    """Narrow widths let thousands of trajectories fit the static workspace; the workspace entry point would split such
+    a call into side-by-side chains on streams of its own (created on first use), the allocation-free one must not:
+    it runs one chain on the caller's stream, and since rows are independent the results are the same bits."""
+    d, salt, B, H = dict(DIMS["small"], D=32, M=32, L=1, A=4), 29, 2048, 1
+    wm, actor, critic = build_models(d, salt)
+    eng = ImagineEngine(wm.to(DEV), actor.to(DEV), critic.to(DEV))
+    assert N.lib().drm_imagine_workspace_bytes(C.byref(eng.dims), B, H) <= (16 << 20)
+    ref = _run(eng, d, salt, B, H)
+    got = _run(eng, d, salt, B, H, noalloc=True)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
