@@ -264,7 +264,7 @@ typedef struct drm_mlp {
 } drm_mlp;
 
 typedef struct drm_dims {
-    int32_t D;   /* recurrent width (hidden_size): multiple of 32, <= 4096 (observe scan: <= 512) */
+    int32_t D;   /* recurrent width (hidden_size): multiple of 32, <= 4096 (the observe scan too: beyond 512 its products run on the large-row kernel) */
     int32_t L;   /* latents */
     int32_t K;   /* classes per latent: must be 32 */
     int32_t M;   /* mlp_hidden_units: multiple of 32, <= 4096 */

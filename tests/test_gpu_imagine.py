@@ -289,12 +289,35 @@ def test_large_batch_properties(precision):
     sub = slice(1000, 1016)
     got = {k: v[:16].cpu() for k, v in part.items()}
     _check_rows_against_oracle(wm, actor, critic, h0[sub], z0[sub], ea[:, sub].cpu(), ez[:, sub].cpu(), got)
+    # rows of the full run itself at other tile positions: either side of the first row-tile boundary (63 | 64), either
+    # side of the boundary between the two chains (2047 | 2048), inside a middle tile and the last rows of the last tile
+    pick = torch.tensor([63, 64, 65, 1500, 1501, 2047, 2048, 2049, 3000, 4032, 4064, 4093, 4094, 4095])
+    got_full = {k: v[pick.to(v.device)].cpu() for k, v in full.items()}
+    _check_rows_against_oracle(wm, actor, critic, h0[pick], z0[pick], ea[:, pick.to(DEV)].cpu(), ez[:, pick.to(DEV)].cpu(), got_full)
     # the small-row kernels on the same 16 rows: same values to tolerance (different summation order)
     small = eng.run(WorldModelState(h=h0[sub].to(DEV), z=z0[sub].to(DEV)), H, 0.997, 0.95,
                     noise={"a": ea[:, sub].contiguous(), "z": ez[:, sub].contiguous()}, want_dense_z=False,
                     forced_actions=part["actions"][:16].contiguous(), forced_zidx=part["zidx"][:16].contiguous())
     for key in ("h", "rewards", "conts", "values", "lam_returns"):
         assert rel_err(small[key].cpu(), got[key]) < TOL, key
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_mfma"])
+def test_large_batch_with_a_ragged_last_tile(precision):
+    """4066 trajectories: 63 full row tiles and one of 34 rows (and no split into two chains: not a multiple of 128).
+    Rows of the last, partial tile and of full tiles against the oracle led along the device's trajectory."""
+    d, salt, B, H = DIMS["default"], 6, 4066, 3
+    wm, actor, critic, eng = _engine(d, salt)
+    h0, z0, _ = start_state(d, salt, B)
+    ea = torch.from_numpy(hash_exponential("ea", (H, B, d["A"]), salt))
+    ez = torch.from_numpy(hash_exponential("ez", (H, B, d["L"], d["K"]), salt))
+    full = eng.run(WorldModelState(h=h0.to(DEV), z=z0.to(DEV)), H, 0.997, 0.95, noise={"a": ea.to(DEV), "z": ez.to(DEV)},
+                   want_dense_z=False, precision=precision)
+    torch.cuda.synchronize()
+    assert torch.isfinite(full["lam_returns"]).all()
+    pick = torch.tensor([0, 63, 64, 2000, 4031, 4032, 4033, 4050, 4064, 4065])
+    got = {k: v[pick.to(v.device)].cpu() for k, v in full.items()}
+    _check_rows_against_oracle(wm, actor, critic, h0[pick], z0[pick], ea[:, pick], ez[:, pick], got)
 
 
 def test_large_batch_split_products_follow_the_fp32_form():
