@@ -357,7 +357,8 @@ def main():
         zidx0 = N.onehot_to_index(z0)
 
         def step():
-            # draws the Exp(1) noise of the block (one generator call for both tensors) and runs the block
+            # runs the block including its Exp(1) noise: one generator launch for both tensors at few trajectories, drawn
+            # inside the kernels (counter-based generator) from 256 trajectories on in the fp32 / split forms
             # "f32" here names the fp32 matrix-instruction form explicitly (the engine's own default at 256 rows and more
             # is the split form, measured as "f32_split")
             return eng.run(start, H, cfg.gamma, cfg.lam, start_zidx=zidx0, repack=repack, persistent=True,

@@ -65,7 +65,8 @@ class drm_imagine_io(C.Structure):
                 ("prior_logits_out", C.c_void_p), ("rewards_out", C.c_void_p), ("conts_out", C.c_void_p),
                 ("values_out", C.c_void_p), ("v_last_out", C.c_void_p), ("lam_returns_out", C.c_void_p),
                 ("gamma", C.c_double), ("lam", C.c_double), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t), ("use_graph", C.c_int32), ("precision", C.c_int32)]
+                ("workspace_bytes", C.c_size_t), ("use_graph", C.c_int32), ("precision", C.c_int32),
+                ("rng_state", C.c_void_p), ("rng_seed", C.c_uint64), ("rng_counter", C.c_uint64)]
 
 
 class drm_observe_weights(C.Structure):
@@ -135,6 +136,8 @@ SIGNATURES = {
     "drm_adam_workspace_bytes": (C.c_size_t, []),
     "drm_adam_flat_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_double] * 5 + [C.c_void_p] * 4),
     "drm_copy_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "drm_copy_pair_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint64,
+                                    C.c_void_p]),
     "drm_fused_linear_f32": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_split": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
@@ -432,15 +435,20 @@ def convt_k4s2_input_grad(grad_y: torch.Tensor, weight: torch.Tensor, channels_l
     return gx
 
 
-def copy_pair(a_dst: torch.Tensor, a_src: torch.Tensor, b_dst: torch.Tensor, b_src: torch.Tensor) -> None:
-    """a_dst <- a_src and b_dst <- b_src (dense tensors of equal byte size each) in one launch."""
+def copy_pair(a_dst: torch.Tensor, a_src: torch.Tensor, b_dst: torch.Tensor, b_src: torch.Tensor,
+              rng_state: Optional[torch.Tensor] = None, rng_counter: int = 0) -> None:
+    """a_dst <- a_src and b_dst <- b_src (dense tensors of equal byte size each) in one launch; with ``rng_state`` (one
+    int64 on the device) the same launch stores ``rng_counter`` there."""
     require_cuda(a_dst)
     for dst, src in ((a_dst, a_src), (b_dst, b_src)):
         if not (dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()):
             raise ValueError("copy_pair needs dense tensors of the same dtype and size")
-    check(lib().drm_copy_pair(a_src.data_ptr(), a_dst.data_ptr(), a_dst.numel() * a_dst.element_size(),
-                              b_src.data_ptr(), b_dst.data_ptr(), b_dst.numel() * b_dst.element_size(),
-                              stream_ptr(a_dst.device)), "drm_copy_pair")
+    if rng_state is not None and not (rng_state.is_cuda and rng_state.dtype == torch.int64 and rng_state.numel() == 1):
+        raise ValueError("rng_state must be one int64 on the device")
+    check(lib().drm_copy_pair_rng(a_src.data_ptr(), a_dst.data_ptr(), a_dst.numel() * a_dst.element_size(),
+                                  b_src.data_ptr(), b_dst.data_ptr(), b_dst.numel() * b_dst.element_size(),
+                                  ptr(rng_state), int(rng_counter) & 0xFFFFFFFFFFFFFFFF, stream_ptr(a_dst.device)),
+          "drm_copy_pair_rng")
 
 
 def fused_linear(x, w, bias=None, ln=None, table=None, zidx=None, classes: int = 32, w_cols=None, bf16: bool = False,

@@ -3,6 +3,7 @@
 // the feature dimension (LayerNorm and the next matmul need whole rows), so each is a kernel
 // boundary; inside a kernel the output columns are spread over the CUs.
 #include "launch.hpp"
+#include "rng.hpp"
 #include "linear_big.hpp"
 
 #include <cstring>
@@ -280,7 +281,8 @@ struct ActorGatesArgs {
     const float* ln_g; const float* ln_b;
     const float* head_w; const float* head_b;
     int M, A;
-    const float* expo; int64_t lde;          // (B, A)
+    const float* expo; int64_t lde;          // (B, A), or nullptr: drawn in the kernel from `rng`
+    RngArgs rng;
     const int64_t* forced; int64_t ldf;      // (B) strided or nullptr
     float one_m_eps, eps_over_a;             // 1 - unimix_eps, unimix_eps / A
     const float* gi_z; int64_t ldgi;         // (B, 3D)
@@ -321,7 +323,16 @@ __global__ __launch_bounds__(256) void k_actor_gates(const ActorGatesArgs P) {
     for (int a = 0; a < AMAX; ++a) hw[a] = ld2(P.head_w + (int64_t)a * P.M + i0, on && a < P.A);
     const int la = lane % AMAX;
     const bool aon = la < P.A;
-    const float ex = aon ? P.expo[(int64_t)b * P.lde + la] : 1.f;
+    float ex = 1.f;
+    if (P.expo != nullptr) {                 // (uniform)
+        if (aon) ex = P.expo[(int64_t)b * P.lde + la];
+    } else {
+        // action `la` of row b: component la % 4 of group la / 4 of the row's (A + 3) / 4 groups
+        const uint64_t row = (uint64_t)P.rng.t * (uint64_t)P.rng.rows_total + (uint64_t)(P.rng.row0 + b);
+        const float4 e4 = rng_exp4(P.rng, 1u, row * (uint64_t)((P.A + 3) >> 2) + (uint64_t)(la >> 2));
+        const int c = la & 3;
+        ex = aon ? (c == 0 ? e4.x : c == 1 ? e4.y : c == 2 ? e4.z : e4.w) : 1.f;
+    }
     const float hb = aon ? P.head_b[la] : 0.f;
     const float* giz = P.gi_z + (int64_t)b * P.ldgi;
     const float* ghp = P.gh + (int64_t)b * P.ldgh;
@@ -487,7 +498,8 @@ __global__ __launch_bounds__(256) void k_scalar_heads(const ScalarHeadsArgs P, c
 // the strided (B, H, ...) outputs of the rollout
 struct SampleRowsArgs {
     const float* logits; int64_t ldlg;       // (B, L*32)
-    const float* expo; int64_t lde;
+    const float* expo; int64_t lde;          // or nullptr: drawn in the kernel from `rng`
+    RngArgs rng;
     const uint8_t* forced; int64_t ldf;
     uint8_t* idx_used; int64_t ldu;
     uint8_t* idx_sampled; int64_t ldsm;
@@ -504,7 +516,9 @@ __global__ __launch_bounds__(256) void k_sample_rows(const SampleRowsArgs P) {
     for (int64_t it = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); it < total; it += (int64_t)gridDim.x * 32) {
         const int b = (int)(it / P.L), l = (int)(it - (int64_t)b * P.L);
         const float4 lg = *reinterpret_cast<const float4*>(P.logits + (int64_t)b * P.ldlg + l * 32 + sub * 4);
-        const float4 ex = *reinterpret_cast<const float4*>(P.expo + (int64_t)b * P.lde + l * 32 + sub * 4);
+        const float4 ex = P.expo != nullptr
+            ? *reinterpret_cast<const float4*>(P.expo + (int64_t)b * P.lde + l * 32 + sub * 4)
+            : rng_exp4(P.rng, 0u, (((uint64_t)P.rng.t * (uint64_t)P.rng.rows_total + (uint64_t)(P.rng.row0 + b)) * (uint64_t)P.L + (uint64_t)l) * 8u + (uint64_t)sub);
         // argmax_k softmax(log_unimix(logits) - log E)_k = argmax_k ((1-eps) softmax(logits)_k + eps/K) / E_k
         const float v[4] = {lg.x, lg.y, lg.z, lg.w};
         const float e[4] = {ex.x, ex.y, ex.z, ex.w};
@@ -571,7 +585,9 @@ __global__ __launch_bounds__(256) void k_sample_gather(const SampleGatherArgs P)
         float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (S.logits != nullptr) {
             lg = *reinterpret_cast<const float4*>(S.logits + (int64_t)b * S.ldlg + l * 32 + sub * 4);
-            const float4 ex = *reinterpret_cast<const float4*>(S.expo + (int64_t)b * S.lde + l * 32 + sub * 4);
+            const float4 ex = S.expo != nullptr
+                ? *reinterpret_cast<const float4*>(S.expo + (int64_t)b * S.lde + l * 32 + sub * 4)
+                : rng_exp4(S.rng, 0u, (((uint64_t)S.rng.t * (uint64_t)S.rng.rows_total + (uint64_t)(S.rng.row0 + b)) * (uint64_t)S.L + (uint64_t)l) * 8u + (uint64_t)sub);
             // argmax_k softmax(log_unimix(logits) - log E)_k = argmax_k ((1-eps) softmax(logits)_k + eps/K) / E_k:
             // the draw needs no logarithm (the log-domain form of lib/world_model.py:459-461 is
             // monotone in this ratio)
@@ -1112,16 +1128,25 @@ static int run_linear(ProblemSpec* p, int np, int M, const uint8_t* zidx, int64_
 
 // One chain of launches for io->B trajectories.  `nb`: rows of a time step in the two noise tensors (io->B unless the
 // trajectories are a slice of a larger call, whose noise is laid out (H, nb, ...)).
-static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream, int nb) {
+static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream, int nb, int row0 = 0) {
     if (int rc = check_weights(*w)) return rc;
     prof_fresh();
     const drm_dims& d = w->dims;
     const int B = io->B, H = io->H, D = d.D, M = d.M, L = d.L, LK = d.L * d.K, S = D + LK;
     DRM_REQUIRE(B >= 1 && H >= 1, DRM_EINVAL, "B=%d H=%d", B, H);
     DRM_REQUIRE((int64_t)B * H < (1 << 30), DRM_ENOTSUP, "B*H too large");
-    DRM_REQUIRE(io->h0 && io->zidx0 && io->expo_a && io->expo_z && io->h_out && io->zidx_out && io->actions_out &&
+    DRM_REQUIRE(io->h0 && io->zidx0 && io->h_out && io->zidx_out && io->actions_out &&
                     io->rewards_out && io->conts_out && io->values_out && io->v_last_out && io->lam_returns_out,
                 DRM_EINVAL, "null io pointer");
+    DRM_REQUIRE((io->expo_a != nullptr) == (io->expo_z != nullptr), DRM_EINVAL, "noise: both tensors or neither");
+    // no noise tensors: the draws take their Exp(1) numbers from the counter-based generator inside the kernels
+    const bool device_rng = io->expo_a == nullptr;
+    RngArgs rng{};
+    rng.seed_lo = (uint32_t)io->rng_seed; rng.seed_hi = (uint32_t)(io->rng_seed >> 32);
+    rng.state = io->rng_state; rng.counter = io->rng_counter; rng.rows_total = nb; rng.row0 = row0;
+    auto rng_at = [&](int t) { RngArgs r = rng; r.t = (uint32_t)t; return r; };
+    auto noise_a = [&](int t) -> const float* { return device_rng ? nullptr : io->expo_a + (size_t)t * nb * w->dims.A; };
+    auto noise_z = [&](int t) -> const float* { return device_rng ? nullptr : io->expo_z + (size_t)t * nb * (size_t)(w->dims.L * w->dims.K); };
     const PackLayout pl = pack_layout(d);
     DRM_REQUIRE(w->pack && w->pack_bytes >= pl.total * sizeof(float), DRM_EINVAL, "weights not packed (drm_pack_imagine)");
     const WsLayout wl = ws_layout(d, B, H);
@@ -1178,7 +1203,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
             if (step_table_add) {
                 if (draw) {
                     SampleRowsArgs a{};
-                    a.logits = ws + wl.logits; a.ldlg = LK; a.expo = io->expo_z + (size_t)t * nb * LK; a.lde = LK;
+                    a.logits = ws + wl.logits; a.ldlg = LK; a.expo = noise_z(t); a.lde = LK; a.rng = rng_at(t);
                     a.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.ldf = (int64_t)H * L;
                     a.idx_used = io->zidx_out + (size_t)t * L; a.ldu = (int64_t)H * L;
                     a.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.ldsm = (int64_t)H * L;
@@ -1211,7 +1236,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
             a.s.B = B; a.s.L = L; a.s.log1m_eps = l1m; a.s.log_eps_over_k = lek;
             a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_k = d.unimix_eps / (float)d.K;
             if (draw) {
-                a.s.logits = ws + wl.logits; a.s.ldlg = LK; a.s.expo = io->expo_z + (size_t)t * nb * LK; a.s.lde = LK;
+                a.s.logits = ws + wl.logits; a.s.ldlg = LK; a.s.expo = noise_z(t); a.s.lde = LK; a.s.rng = rng_at(t);
                 a.s.forced = io->forced_zidx ? io->forced_zidx + (size_t)t * L : nullptr; a.s.ldf = (int64_t)H * L;
                 a.s.idx_used = io->zidx_out + (size_t)t * L; a.s.ldu = (int64_t)H * L;
                 a.s.idx_sampled = io->zidx_sampled_out ? io->zidx_sampled_out + (size_t)t * L : nullptr; a.s.ldsm = (int64_t)H * L;
@@ -1271,7 +1296,7 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
                 a.pre = ws + wl.a_pre[last_a & 1]; a.ldp = M;
                 a.ln_g = w->actor.ln_g[last_a]; a.ln_b = w->actor.ln_b[last_a];
                 a.head_w = w->actor.head_w; a.head_b = w->actor.head_b; a.M = M; a.A = d.A;
-                a.expo = io->expo_a + (size_t)t * nb * d.A; a.lde = d.A;
+                a.expo = noise_a(t); a.lde = d.A; a.rng = rng_at(t);
                 a.forced = io->forced_actions ? io->forced_actions + t : nullptr; a.ldf = H;
                 a.one_m_eps = 1.0f - d.unimix_eps; a.eps_over_a = d.unimix_eps / (float)d.A;
                 a.gi_z = ws + wl.gi; a.ldgi = 3 * D; a.gi_a = pack + pl.gi_a; a.b_ih = w->gru_b_ih;
@@ -1313,6 +1338,8 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
             if (int rc = sample_gather(t, true, t + 1 < H)) return rc;
         }
     } else {
+    DRM_REQUIRE(!device_rng, DRM_ENOTSUP, "in-kernel noise is built into the step-wise launch sequence only (few rows, or many rows at "
+                "widths up to 512 with fp32 / split products): pass expo_a / expo_z for this shape");
     // gh for step 0
     {
         ProblemSpec p{io->h0, D, nullptr, nullptr, w->gru_w_hh, D, w->gru_b_hh, nullptr, 0, ws + wl.gh, 3 * D, 3 * D, D};
@@ -1554,7 +1581,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
         drm_imagine_io p = *io;
         p.B = half;
         p.h0 = io->h0 + b0 * d.D; p.zidx0 = io->zidx0 + b0 * d.L;
-        p.expo_a = io->expo_a + b0 * d.A; p.expo_z = io->expo_z + b0 * LK;
+        if (io->expo_a) { p.expo_a = io->expo_a + b0 * d.A; p.expo_z = io->expo_z + b0 * LK; }
         if (io->forced_actions) p.forced_actions = io->forced_actions + b0 * H;
         if (io->forced_zidx) p.forced_zidx = io->forced_zidx + b0 * H * d.L;
         p.h_out = io->h_out + b0 * H * d.D; p.zidx_out = io->zidx_out + b0 * H * d.L;
@@ -1567,7 +1594,7 @@ static int imagine_enqueue(const drm_imagine_weights* w, const drm_imagine_io* i
         if (io->actions_sampled_out) p.actions_sampled_out = io->actions_sampled_out + b0 * H;
         if (io->zidx_sampled_out) p.zidx_sampled_out = io->zidx_sampled_out + b0 * H * d.L;
         p.workspace = (char*)io->workspace + i * part_bytes; p.workspace_bytes = part_bytes;
-        rc = imagine_enqueue_part(w, &p, (drm_stream_t)c.s[i], B);
+        rc = imagine_enqueue_part(w, &p, (drm_stream_t)c.s[i], B, (int)b0);
         // joined even after a failure: a recording must not end with a dangling branch
         if (hipEventRecord(c.join[i], c.s[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.join[i], 0);
     }

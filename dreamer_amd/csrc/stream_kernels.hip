@@ -379,8 +379,10 @@ extern "C" int drm_onehot_to_index(const float* z, int64_t rows, int32_t K, uint
 namespace drm {
 __global__ __launch_bounds__(256) void k_copy_pair(const uint8_t* __restrict__ a_src, uint8_t* __restrict__ a_dst, size_t a_bytes,
                                                     const uint8_t* __restrict__ b_src, uint8_t* __restrict__ b_dst, size_t b_bytes,
-                                                    int vec) {
+                                                    int vec, unsigned long long* __restrict__ rng_state,
+                                                    unsigned long long rng_counter) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    if (tid == 0 && rng_state != nullptr) *rng_state = rng_counter;
     if (vec) {   // all pointers and sizes are multiples of 16
         const size_t na = a_bytes / 16, nb = b_bytes / 16;
         for (size_t i = tid; i < na + nb; i += step) {
@@ -396,18 +398,26 @@ __global__ __launch_bounds__(256) void k_copy_pair(const uint8_t* __restrict__ a
 }
 }  // namespace drm
 
-extern "C" int drm_copy_pair(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
-                             drm_stream_t stream) {
+extern "C" int drm_copy_pair_rng(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
+                                 uint64_t* rng_state, uint64_t rng_counter, drm_stream_t stream) {
     DRM_REQUIRE((a_bytes == 0 || (a_src && a_dst)) && (b_bytes == 0 || (b_src && b_dst)), DRM_EINVAL, "null pointer");
-    if (a_bytes + b_bytes == 0) return DRM_OK;
+    if (a_bytes + b_bytes == 0 && rng_state == nullptr) return DRM_OK;
     const bool vec = aligned16(a_src) && aligned16(a_dst) && aligned16(b_src) && aligned16(b_dst) && a_bytes % 16 == 0 &&
                      b_bytes % 16 == 0;
     const size_t units = vec ? (a_bytes + b_bytes) / 16 : a_bytes + b_bytes;
     size_t blocks = (units + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
     ProfScope prof(PC_ELEMENTWISE, (hipStream_t)stream, 0.0, 2.0 * (double)(a_bytes + b_bytes));
     k_copy_pair<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-        (const uint8_t*)a_src, (uint8_t*)a_dst, a_bytes, (const uint8_t*)b_src, (uint8_t*)b_dst, b_bytes, vec ? 1 : 0);
+        (const uint8_t*)a_src, (uint8_t*)a_dst, a_bytes, (const uint8_t*)b_src, (uint8_t*)b_dst, b_bytes, vec ? 1 : 0,
+        (unsigned long long*)rng_state, (unsigned long long)rng_counter);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
+}
+
+extern "C" int drm_copy_pair(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
+                             drm_stream_t stream) {
+    if (a_bytes + b_bytes == 0) return DRM_OK;
+    return drm_copy_pair_rng(a_src, a_dst, a_bytes, b_src, b_dst, b_bytes, nullptr, 0, stream);
 }

@@ -128,6 +128,24 @@ class ImagineEngine:
             out["actions_sampled"] = torch.empty(B, H, dtype=torch.int64, device=dev)
         return out
 
+    def _device_noise_ok(self, B: int, precision_code: int) -> bool:
+        """Whether the in-kernel generator serves this shape: the step-wise launch sequence (at most 64 trajectories, or
+        256 and more with fp32 / split products) at widths up to 512."""
+        d = self.dims
+        if os.environ.get("DRM_HOST_NOISE", "0") == "1" or d.D > 512 or d.M > 512:
+            return False
+        if B <= 64:
+            return True
+        return (B >= 256 and precision_code in (0, 2) and d.L <= 64 and os.environ.get("DRM_NO_FUSED_STEP") is None)
+
+    def _reserve_noise(self):
+        """(seed, counter) for one call: the device generator's seed and its current offset, which is advanced as a torch
+        kernel that draws would advance it -- the generator's state covers the in-kernel draws too."""
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+        offset = int(gen.get_offset())
+        gen.set_offset(offset + 4)
+        return int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF, offset
+
     @torch.no_grad()
     def _noise_buffer(self, B: int, H: int):
         """Action noise (H,B,A) and latent noise (H,B,L,K) as views of one buffer, so that a single
@@ -143,7 +161,7 @@ class ImagineEngine:
             forced_zidx: Optional[torch.Tensor] = None, want_dense_z: bool = True, want_logp: bool = True,
             want_prior_logits: bool = False, want_sampled: bool = False, start_zidx: Optional[torch.Tensor] = None,
             repack: bool = True, persistent: bool = False, precision: str = "f32",
-            noalloc: bool = False) -> Dict[str, torch.Tensor]:
+            noalloc: bool = False, device_noise: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """Run the block.  With ``persistent=True`` all inputs are staged into, and all outputs
         returned as, buffers that live as long as the engine (overwritten by the next call with the
         same shape); every device address is then the same from call to call and the native side
@@ -154,7 +172,13 @@ class ImagineEngine:
         ``"f32"`` mean ``"f32_mfma"`` everywhere).  ``precision="bf16"``: the matrix products of the large-row path take
         bf16 inputs (fp32 accumulation, everything else fp32).
         ``noalloc=True``: the library's entry point that takes no workspace (it uses a static device array of its own,
-        for at most a few dozen trajectories) and never records a graph."""
+        for at most a few dozen trajectories) and never records a graph.
+        Noise: ``noise`` given -> those Exp(1) tensors (parity tests).  Otherwise either one ``exponential_`` launch fills
+        noise tensors, or the draws take their numbers from the counter-based generator inside the kernels, keyed by
+        torch's device seed and addressed by a block of the device generator's offset reserved per call (so
+        ``torch.manual_seed`` and a restored generator state reproduce a run either way).  ``device_noise=None`` picks
+        the faster of the two: in-kernel from 256 trajectories on, the launch below (``True`` / ``DRM_DEVICE_NOISE=1``:
+        in-kernel wherever the step-wise launch sequence runs; ``False`` / ``DRM_HOST_NOISE=1``: always the launch)."""
         d, dev = self.dims, self.device
         B, H = start.h.shape[0], int(horizon)
         if repack:
@@ -171,30 +195,51 @@ class ImagineEngine:
         out = slot["out"]
         h0 = start.h.detach()
         zidx0 = start_zidx if start_zidx is not None else N.onehot_to_index(start.z.detach().contiguous().float())
+        prec = resolve_precision(precision, B, d.D, d.M)
+        # measured on one MI355X: drawing inside the kernels wins from 256 trajectories on (B = 4096: 6.88 against 7.00 ms per
+        # block, no 250 MB of noise to write and read); at 16 trajectories the generator's arithmetic sits on the critical
+        # path of the draw kernels and costs what the noise launch cost (0.573 against 0.566 ms), so few rows keep the launch
+        prefer = device_noise if device_noise is not None else (B >= 256 or os.environ.get("DRM_DEVICE_NOISE", "0") == "1")
+        in_kernel = noise is None and prefer and self._device_noise_ok(B, prec)
+        rng_seed = rng_counter = 0
+        rng_state = None
+        if in_kernel:
+            rng_seed, rng_counter = self._reserve_noise()
+        ea = ez = None
         if persistent:
+            if in_kernel and "rng" not in slot:
+                slot["rng"] = torch.zeros(1, dtype=torch.int64, device=dev)
+            rng_state = slot["rng"] if in_kernel else None
             if h0.dtype == torch.float32 and h0.is_contiguous() and zidx0.is_contiguous():
-                N.copy_pair(slot["h0"], h0, slot["zidx0"], zidx0)
+                N.copy_pair(slot["h0"], h0, slot["zidx0"], zidx0, rng_state, rng_counter)
             else:
                 slot["h0"].copy_(h0)
                 slot["zidx0"].copy_(zidx0)
+                if in_kernel:
+                    rng_state.fill_(rng_counter - (1 << 64) if rng_counter >= (1 << 63) else rng_counter)
             h0, zidx0 = slot["h0"], slot["zidx0"]
-            if noise is None:
+            if in_kernel:
+                rng_counter = 0          # read from the device word: the recorded launches keep their arguments
+            elif noise is None:
                 slot["noise"].exponential_()
                 ea, ez = slot["ea"], slot["ez"]
             else:
                 ea, ez = slot["ea"].copy_(noise["a"]), slot["ez"].copy_(noise["z"])
         else:
             h0 = h0.contiguous().float()
-            if noise is None:
+            if in_kernel:
+                pass
+            elif noise is None:
                 flat, ea, ez = self._noise_buffer(B, H)
                 flat.exponential_()
             else:
                 ea, ez = noise["a"].contiguous(), noise["z"].contiguous()
-        assert ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K)
+        assert in_kernel or (ea.shape == (H, B, d.A) and ez.shape == (H, B, d.L, d.K))
         ws = None if noalloc else self._workspace(B, H)
         io = N.drm_imagine_io()
         io.B, io.H = B, H
-        io.h0, io.zidx0, io.expo_a, io.expo_z = h0.data_ptr(), zidx0.data_ptr(), ea.data_ptr(), ez.data_ptr()
+        io.h0, io.zidx0, io.expo_a, io.expo_z = h0.data_ptr(), zidx0.data_ptr(), N.ptr(ea), N.ptr(ez)
+        io.rng_state, io.rng_seed, io.rng_counter = N.ptr(rng_state), rng_seed, rng_counter
         io.forced_actions = N.ptr(forced_actions.contiguous() if forced_actions is not None else None)
         io.forced_zidx = N.ptr(forced_zidx.contiguous() if forced_zidx is not None else None)
         io.h_out, io.zidx_out, io.actions_out = out["h"].data_ptr(), out["zidx"].data_ptr(), out["actions"].data_ptr()
@@ -205,7 +250,7 @@ class ImagineEngine:
                                                        out["values"].data_ptr())
         io.v_last_out, io.lam_returns_out = out["v_last"].data_ptr(), out["lam_returns"].data_ptr()
         io.gamma, io.lam = float(gamma), float(lam)
-        io.precision = resolve_precision(precision, B, d.D, d.M)
+        io.precision = prec
         w = self._weights()
         if noalloc:
             io.workspace, io.workspace_bytes, io.use_graph = None, 0, 0

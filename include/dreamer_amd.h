@@ -201,6 +201,10 @@ int drm_adam_flat_step(float* params, const float* grads, float* exp_avg, float*
  * not overlap. */
 int drm_copy_pair(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
                   drm_stream_t stream);
+/* The same, and `*rng_state = rng_counter` from the same launch (the call counter a graph-replayed block with in-kernel
+ * noise reads, see drm_imagine_io). */
+int drm_copy_pair_rng(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
+                      uint64_t* rng_state, uint64_t rng_counter, drm_stream_t stream);
 
 /* ---- fused linear block (building block of every step below) --------------------------------
  * Y[m, n] = bias[n] + sum_k f(X)[m,k] * W[n,k] + sum_l table[(l*classes + zidx[m,l]), n]
@@ -303,8 +307,8 @@ typedef struct drm_imagine_io {
     int32_t B, H;
     const float* h0;               /* (B,D) start recurrent state */
     const uint8_t* zidx0;          /* (B,L) start latent class indices */
-    const float* expo_a;           /* (H,B,A) Exp(1) for the action draw of each step */
-    const float* expo_z;           /* (H,B,L,K) Exp(1) for the latent draw of each step */
+    const float* expo_a;           /* (H,B,A) Exp(1) for the action draw of each step, or NULL (then expo_z too): the */
+    const float* expo_z;           /* (H,B,L,K) Exp(1) for the latent draw of each step    draws use rng_* below */
     const int64_t* forced_actions; /* (B,H) or NULL: use these instead of the sampled actions */
     const uint8_t* forced_zidx;    /* (B,H,L) or NULL: use these instead of the sampled latents */
     float* h_out;                  /* (B,H,D) */
@@ -332,6 +336,15 @@ typedef struct drm_imagine_io {
                                       of both operands (see drm_fused_linear_split); at widths up to 512 the
                                       faster of the two fp32-accurate forms from 256 trajectories on (the Python
                                       engine's default there) */
+    /* Noise drawn inside the kernels (expo_a == expo_z == NULL; lib/world_model.py:459-461 and lib/trainer.py:190-191
+     * draw it through torch's generator): Exp(1) values from Philox-4x32-10 keyed by rng_seed and addressed by
+     * (call counter, kind of draw, step, trajectory, element).  The call counter is read from the device word
+     * *rng_state when rng_state != NULL (a replayed graph then draws fresh numbers whenever the caller has stored a new
+     * counter there, e.g. with drm_copy_pair_rng), else it is rng_counter.  Same counter and seed: same draws.  Built
+     * into the step-wise launch sequence (B <= 64 at widths <= 512, or B >= 256 at widths <= 512 with precision 0 / 2);
+     * other shapes return DRM_ENOTSUP without noise tensors. */
+    const uint64_t* rng_state;
+    uint64_t rng_seed, rng_counter;
 } drm_imagine_io;
 
 size_t drm_imagine_workspace_bytes(const drm_dims* dims, int32_t B, int32_t H);
