@@ -73,7 +73,7 @@ def pmc_traffic(workload, cls):
     (FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE counts 16-byte-per-lane reads at half their
     size on gfx950 and is doubled), and the file they were read from.  (None, None) when no pass of this
     workload is on file."""
-    for rel in ("profiles/r2_pmc.json", "profiles/r1_pmc.json"):
+    for rel in ("profiles/r3_pmc.json", "profiles/r2_pmc.json", "profiles/r1_pmc.json"):
         path = os.path.join(ROOT, rel)
         if os.path.exists(path):
             break

@@ -30,6 +30,15 @@ pmc() {  # name, counter, bench args...
     rm -rf "$out/$name.$ctr"
 }
 
+# several counters of one block in one pass (at most 8 SQ_ counters): name, file tag, "CTR1 CTR2", bench args...
+pmc_multi() {
+    local name=$1; local tag=$2; local ctrs=$3; shift; shift; shift
+    DRM_NO_TWO_CHAINS=1 timeout -s KILL 200 rocprofv3 --pmc $ctrs -d "$out/$name.$tag" -o "$name" --output-format csv -- \
+        python3 "$root/bench.py" --no-cpu-baseline --no-stream-kernels --no-extras --train-steps 0 --profile-steps 0 "$@" > /dev/null 2> "$out/$name.$tag.err"
+    python3 "$root/tools/pmc_summary.py" "$out/$name.$tag" $ctrs > "$out/$name.$tag.txt"
+    rm -rf "$out/$name.$tag"
+}
+
 stats imagine16 --workload imagine16
 stats imagine4096 --workload imagine4096 --steps 20 --warmup 3
 pmc imagine4096 FETCH_SIZE --workload imagine4096 --steps 3 --warmup 1
@@ -38,5 +47,9 @@ pmc imagine16 FETCH_SIZE --workload imagine16 --steps 10 --warmup 2
 pmc imagine16 WRITE_SIZE --workload imagine16 --steps 10 --warmup 2
 stats imagine4096_bf16 --workload imagine4096_bf16 --steps 20 --warmup 3
 stats imagine4096_split --workload imagine4096_split --steps 20 --warmup 3
+pmc imagine4096_split FETCH_SIZE --workload imagine4096_split --steps 3 --warmup 1
+pmc imagine4096_split WRITE_SIZE --workload imagine4096_split --steps 3 --warmup 1
+pmc_multi imagine4096 SQ_counters "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" --workload imagine4096 --steps 3 --warmup 1
+pmc_multi imagine4096_split SQ_counters "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" --workload imagine4096_split --steps 3 --warmup 1
 python3 "$root/tools/pmc_to_json.py" "$out" "$out/pmc.json"
 echo done
