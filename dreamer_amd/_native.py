@@ -152,6 +152,7 @@ SIGNATURES = {
     "drm_imagine_block_noalloc_f32": (C.c_int, [C.POINTER(drm_imagine_weights), C.POINTER(drm_imagine_io), C.c_void_p]),
     "drm_pack_observe_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
     "drm_pack_observe": (C.c_int, [C.POINTER(drm_observe_weights), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "drm_pack_observe_prec": (C.c_int, [C.POINTER(drm_observe_weights), C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "drm_observe_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32, C.c_int32]),
     "drm_observe_forward_f32": (C.c_int, [C.POINTER(drm_observe_weights), C.POINTER(drm_observe_io), C.c_void_p]),
     "drm_observe_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(drm_dims), C.c_int32]),

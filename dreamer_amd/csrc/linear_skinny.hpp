@@ -383,9 +383,13 @@ __global__ __launch_bounds__(256) void k_skinny_mfma(const SkinnyLoopLaunch L) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nblk = (K + KB - 1) / KB, last = nblk - 1;
+    // workgroups start their walk over K at different blocks, so that at any moment the chip's requests are spread over
+    // the whole width of the rows (and with them over the memory channels) instead of one 256-byte column of every row
+    const int rot = (int)(blockIdx.x % (unsigned)nblk);
+#define SKM_RB(blk) ((blk) < nblk ? ((blk) + rot >= nblk ? (blk) + rot - nblk : (blk) + rot) : last)
 #define SKM_LOAD(S, blk)                                                                               \
     {                                                                                                  \
-        const int kb = min((blk), last) * KB;                                                          \
+        const int kb = SKM_RB(blk) * KB;                                                               \
         const int ckw = min(kb + KW * (lane & 15), K - KW), ckx = min(kb + 4 * xq, K - 4);             \
         _Pragma("unroll") for (int i = 0; i < NWL; ++i) {                                              \
             if (MODE == 2) hv[S][i] = *reinterpret_cast<const skm_u32x4*>(hrow[i] + ckw);              \
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(256) void k_skinny_mfma(const SkinnyLoopLaunch L) {
     // registers -> LDS; weights beyond K (or of a block past the end) become zeros, so what X holds there does not count
 #define SKM_STAGE(S, blk)                                                                              \
     {                                                                                                  \
-        const bool valid = (blk) < nblk && (blk) * KB + KW * (lane & 15) < K;                          \
+        const bool valid = (blk) < nblk && SKM_RB(blk) * KB + KW * (lane & 15) < K;                    \
         _Pragma("unroll") for (int i = 0; i < NWL; ++i) {                                              \
             float* dst = sw + (4 * i + (lane >> 4)) * LDR + 4 * (lane & 15);                           \
             if (MODE == 2) {                                                                           \
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(256) void k_skinny_mfma(const SkinnyLoopLaunch L) {
         wave_lds_sync();
     }
 #undef SKM_LOAD
+#undef SKM_RB
 #undef SKM_STAGE
 #undef SKM_MMA
     __syncthreads();

@@ -33,7 +33,8 @@ struct ResetArgs {
     float* x; int64_t ldxo;
 };
 
-// One workgroup per sequence; a thread owns columns tid, tid + 256, ...
+// Workgroup (sequence, slice): a thread owns columns 512 y + tid, + 256 of every gridDim.y-th 512-column slice (every
+// slice's workgroup repeats the small reset draw rather than wait for another one; slice 0 writes it out)
 template <int LMAX>
 __global__ __launch_bounds__(256) void k_observe_reset_x(const ResetArgs P) {
     __shared__ uint8_t s_z[LMAX];
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(256) void k_observe_reset_x(const ResetArgs P) {
         }
     }
     __syncthreads();
-    if (tid < P.L) P.z_in[(int64_t)b * P.ldzi + tid] = s_z[tid];
-    for (int i0 = 0; i0 < P.D; i0 += 512) {
+    if (tid < P.L && blockIdx.y == 0) P.z_in[(int64_t)b * P.ldzi + tid] = s_z[tid];
+    for (int i0 = blockIdx.y * 512; i0 < P.D; i0 += 512 * gridDim.y) {
         const int c0 = i0 + tid, c1 = i0 + tid + 256;
         const bool jn0 = c0 < P.D, jn1 = c1 < P.D;
         const float hp0 = jn0 ? P.h_prev[(int64_t)b * P.ldh + c0] : 0.f, hp1 = jn1 ? P.h_prev[(int64_t)b * P.ldh + c1] : 0.f;
@@ -514,8 +515,8 @@ static int observe_enqueue(const drm_observe_weights* w, const drm_observe_io* i
                 a.z_in = io->zidx_in_out + (size_t)t * L; a.ldzi = TL;
                 a.h_in = io->h_in_out + (size_t)t * D; a.ldhi = TD; a.x = io->x_out + (size_t)t * D; a.ldxo = TD;
                 ProfScope prof(PC_ACTOR_HEAD, s, (double)B * D * (L + 2), 4.0 * (double)B * D * (L + 4));
-                if (L <= 32) k_observe_reset_x<32><<<dim3(B), dim3(256), 0, s>>>(a);
-                else k_observe_reset_x<64><<<dim3(B), dim3(256), 0, s>>>(a);
+                if (L <= 32) k_observe_reset_x<32><<<dim3(B, (D + 511) / 512), dim3(256), 0, s>>>(a);
+                else k_observe_reset_x<64><<<dim3(B, (D + 511) / 512), dim3(256), 0, s>>>(a);
                 DRM_LAUNCH_CHECK();
             }
             {
@@ -619,8 +620,8 @@ static int observe_enqueue(const drm_observe_weights* w, const drm_observe_io* i
             a.D = D; a.L = L; a.classes = d.K;
             a.z_in = zin_t; a.ldzi = TL; a.h_in = hin_t; a.ldhi = TD; a.x = x_t; a.ldxo = TD;
             ProfScope prof(PC_ACTOR_HEAD, s, (double)B * D * (L + 2), 4.0 * (double)B * D * (L + 4));
-            if (L <= 32) k_observe_reset_x<32><<<dim3(B), dim3(256), 0, s>>>(a);
-            else k_observe_reset_x<64><<<dim3(B), dim3(256), 0, s>>>(a);
+            if (L <= 32) k_observe_reset_x<32><<<dim3(B, (D + 511) / 512), dim3(256), 0, s>>>(a);
+            else k_observe_reset_x<64><<<dim3(B, (D + 511) / 512), dim3(256), 0, s>>>(a);
             DRM_LAUNCH_CHECK();
         }
         float* h_t = io->h_out + (size_t)t * D;
@@ -661,7 +662,13 @@ extern "C" size_t drm_pack_observe_bytes(const drm_dims* dims) {
 }
 
 extern "C" int drm_pack_observe(const drm_observe_weights* w, float* pack_out, size_t pack_bytes, drm_stream_t stream) {
+    return drm_pack_observe_prec(w, pack_out, pack_bytes, 0, stream);
+}
+
+extern "C" int drm_pack_observe_prec(const drm_observe_weights* w, float* pack_out, size_t pack_bytes, int32_t precision,
+                                     drm_stream_t stream) {
     DRM_REQUIRE(w && pack_out, DRM_EINVAL, "null pointer");
+    DRM_REQUIRE(precision == 0 || precision == 1, DRM_EINVAL, "precision=%d", precision);
     if (int rc = check_observe_dims(w->dims)) return rc;
     const drm_dims& d = w->dims;
     const ObsPack pl = obs_pack_layout(d);
@@ -682,7 +689,7 @@ extern "C" int drm_pack_observe(const drm_observe_weights* w, float* pack_out, s
     DRM_REQUIRE(w->gru_w_ih, DRM_EINVAL, "null weight");
     ProblemSpec gz{pack_out + pl.lin_zT, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
                    pack_out + pl.gz, 3 * d.D, 3 * d.D, d.D};
-    if (int rc = launch_big(&gz, 1, LK, nullptr, 0, 0, 0, s)) return rc;
+    if (int rc = launch_big(&gz, 1, LK, nullptr, 0, 0, 0, s, d.D > 512 ? precision : 0)) return rc;
     if (d.D > 512) return DRM_OK;      // the wide path forms gi = W_ih x per step; it reads gz only (backward pass)
     ProblemSpec ga{pack_out + pl.a_tab, d.D, nullptr, nullptr, w->gru_w_ih, d.D, nullptr, nullptr, 0,
                    pack_out + pl.ga, 3 * d.D, 3 * d.D, d.D};

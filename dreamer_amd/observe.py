@@ -43,6 +43,19 @@ def _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state):
     return torch.stack(hs, 1), torch.stack(zs, 1), torch.stack(posts, 1), WorldModelState(h=h, z=z)
 
 
+def _wgrad_bf16_ok(dy, D):
+    """Shapes the bf16 large-row kernel takes for dy.T @ x: a long sum over the rows, many output rows."""
+    rows, n = dy.shape
+    return D > 512 and rows >= 256 and rows % 32 == 0 and n >= 256
+
+
+def _wgrad_bf16(dy, x):
+    """dy.T @ x with bf16 matrix inputs and fp32 accumulation: both operands transposed once so that the sum over the
+    rows runs along contiguous memory, then one launch of the large-row kernel (output rows = columns of dy)."""
+    from . import _native as N
+    return N.fused_linear(dy.t().contiguous(), x.t().contiguous(), bf16=True)
+
+
 class _ObserveEngine:
     """Packed tables and workspace of one world model for the native scan."""
 
@@ -84,8 +97,8 @@ class ObserveScanFn(torch.autograd.Function):
         dev = e_part.device
         e_part = e_part.contiguous()
         w = eng.weights(a_emb, lin_w, lin_b, w_ih, w_hh, b_ih, b_hh, fc_w_h)
-        N.check(N.lib().drm_pack_observe(C.byref(w), eng.pack.data_ptr(), eng.pack.numel() * 4, N.stream_ptr(dev)),
-                "drm_pack_observe")
+        N.check(N.lib().drm_pack_observe_prec(C.byref(w), eng.pack.data_ptr(), eng.pack.numel() * 4, eng.precision,
+                                              N.stream_ptr(dev)), "drm_pack_observe_prec")
         f32 = dict(dtype=torch.float32, device=dev)
         u8 = dict(dtype=torch.uint8, device=dev)
         h = torch.empty(B, T, D, **f32); zidx = torch.empty(B, T, L, **u8); zidx_in = torch.empty(B, T, L, **u8)
@@ -155,8 +168,10 @@ class ObserveScanFn(torch.autograd.Function):
         from .world_model import _mm_dgrad, _mm_wgrad
         z_in = F.one_hot(zidx_in.reshape(B * T, L).long(), K).to(h.dtype).reshape(B * T, LK)
         a_vec = a_emb[a2] * c2
-        g_w_ih = _mm_wgrad(gi2, x.reshape(B * T, D))
-        g_w_hh = _mm_wgrad(gh2, h_in.reshape(B * T, D))
+        # the two products over the recurrent width: with bf16 matrix inputs when the scan ran that way
+        wide_wgrad = _wgrad_bf16 if eng.precision == 1 and _wgrad_bf16_ok(gi2, D) else _mm_wgrad
+        g_w_ih = wide_wgrad(gi2, x.reshape(B * T, D))
+        g_w_hh = wide_wgrad(gh2, h_in.reshape(B * T, D))
         g_lin_w = torch.cat([_mm_wgrad(dx2, z_in), _mm_wgrad(dx2, a_vec)], dim=1)
         g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, _mm_dgrad(dx2, lin_w[:, LK:]) * c2)
         g_fc = _mm_wgrad(d_post.reshape(B * T, LK), h.reshape(B * T, D))

@@ -394,6 +394,9 @@ typedef struct drm_observe_weights {
 
 size_t drm_pack_observe_bytes(const drm_dims* dims);
 int drm_pack_observe(const drm_observe_weights* w, float* pack_out, size_t pack_bytes, drm_stream_t stream);
+/* The same with the matrix product that fills the (latent, class) table of GRU input rows in the precision of the scan that
+ * will read it (drm_observe_io.precision: 0 fp32, 1 bf16 matrix inputs with fp32 accumulation). */
+int drm_pack_observe_prec(const drm_observe_weights* w, float* pack_out, size_t pack_bytes, int32_t precision, drm_stream_t stream);
 
 typedef struct drm_observe_io {
     int32_t B, T;

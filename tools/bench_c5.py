@@ -43,11 +43,11 @@ def update():
 
 
 ONLY = os.environ.get("C5_ONLY", "")          # "imagine16": just the few-row imagination block (for kernel traces)
-for prec in (("f32",) if ONLY == "wm" else () if ONLY else ("f32", "bf16")):
+for prec in (("f32",) if ONLY == "wm" else ("bf16",) if ONLY == "wm_bf16" else () if ONLY else ("f32", "bf16")):
     wm.observe_precision = prec
     out[f"wm_loss_backward_ms_16x64_{prec}"] = timeit(update, 5)
     print(prec, "world-model loss + backward: %.2f ms" % out[f"wm_loss_backward_ms_16x64_{prec}"], flush=True)
-if ONLY == "wm":
+if ONLY in ("wm", "wm_bf16"):
     print(json.dumps(out))
     sys.exit(0)
 eng = ImagineEngine(wm, actor, critic)
