@@ -1,6 +1,7 @@
 """Times of the towers' LayerNorm + SiLU kernels at the training shapes, plain and channels-last."""
+import os, sys
 import torch
-
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreamer_amd import _native as N
 
 dev = "cuda:0"
@@ -31,5 +32,8 @@ for c, hw in ((32, 32), (64, 16), (128, 8), (256, 4)):
         tf = t(lambda: N.ln_silu_forward(x, g, b, 1e-5, cb))
         tb = t(lambda: N.ln_silu_backward(x, dy, g, b, mean, rstd, cb))
         mb = x.numel() * 4 / 1e6
-        print(f"C={c:3d} {hw:2d}x{hw:<2d} {'channels-last' if cl else 'plain        '} forward {tf:6.1f} us ({2 * mb / tf * 1e-6 * 1e6 / 1e3:5.2f} TB/s)  "
-              f"backward {tb:6.1f} us ({5 * mb / tb / 1e3:5.2f} TB/s of 5 tensor passes)")
+        if os.environ.get("LN_NO_BIAS"):
+            tf0 = t(lambda: N.ln_silu_forward(x, g, b, 1e-5, None))
+            print(f"    without the channel bias: forward {tf0:6.1f} us")
+        print(f"C={c:3d} {hw:2d}x{hw:<2d} {'channels-last' if cl else 'plain        '} forward {tf:6.1f} us ({2 * mb / tf:5.2f} TB/s)  "
+              f"backward {tb:6.1f} us ({5 * mb / tb:5.2f} TB/s over 5 tensor passes)")
