@@ -885,7 +885,10 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         for (int i = 0; i < np && presplit; ++i) presplit = (L.p[i].Ws = split_planes_of(specs[i], stream)) != nullptr;
     }
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
-    const dim3 grid(tiles, (M + BIG_BM - 1) / BIG_BM);
+    // split form with plenty of tiles: 128-row tiles (two row tiles per wave against the same weight fragments)
+    static const int tall_min = [] { const char* e = std::getenv("DRM_SPLIT_TALL_MIN_TILES"); return e ? atoi(e) : 512; }();
+    const bool tall = precision == 2 && presplit && !narrow && (int64_t)tiles * ((M + 127) / 128) >= tall_min;
+    const dim3 grid(tiles, tall ? (M + 127) / 128 : (M + BIG_BM - 1) / BIG_BM);
     if (precision == 1 && presplit) k_linear_big_bf16<true><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 1) k_linear_big_bf16<false><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2) {
@@ -893,7 +896,10 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         for (int i = 0; i < np; ++i) any_ln = any_ln || specs[i].ln_g != nullptr;
 #define DRM_SPLIT(PRE, NTV) { if (any_ln) k_linear_big_split<PRE, NTV, true><<<grid, dim3(256), 0, stream>>>(L); \
                               else k_linear_big_split<PRE, NTV, false><<<grid, dim3(256), 0, stream>>>(L); }
-        if (presplit && narrow) DRM_SPLIT(true, 1) else if (presplit) DRM_SPLIT(true, 2) else if (narrow) DRM_SPLIT(false, 1) else DRM_SPLIT(false, 2)
+        if (tall) {
+            if (any_ln) k_linear_big_split<true, 2, true, 2><<<grid, dim3(256), 0, stream>>>(L);
+            else k_linear_big_split<true, 2, false, 2><<<grid, dim3(256), 0, stream>>>(L);
+        } else if (presplit && narrow) DRM_SPLIT(true, 1) else if (presplit) DRM_SPLIT(true, 2) else if (narrow) DRM_SPLIT(false, 1) else DRM_SPLIT(false, 2)
 #undef DRM_SPLIT
     } else {
         // fp32 form: a workgroup walks several tiles when no problem needs the epilogue through LDS and every K is an

@@ -573,15 +573,17 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
 // shared by every row tile and every step of a rollout), so only the activation operand is split here.
 // NT = 32-column accumulators per wave: 2 -> 64 x 128 tile, 1 -> 64 x 64 tile (launches whose 128-column grid would
 // put a single workgroup on a CU).
+// MT = 2: 128 x 128 tile, every wave two row tiles (rows 32 wm ... and 64 + 32 wm ...) against the same weight fragments:
+// 12 LDS fragment reads per 24 MFMAs instead of 9 per 12 -- for launches with enough tiles to fill the CUs that way.
 // LNT: the consumer normalises, as in k_linear_big<., true> -- LayerNorm + SiLU of the X rows between the global load and
 // the split, from the row statistics the producer left behind (a problem without ln_g in the same launch loads as before).
-template <bool PRESPLIT, int NT, bool LNT>
+template <bool PRESPLIT, int NT, bool LNT, int MT = 1>
 __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
-    constexpr int BN = 64 * NT;
-    constexpr int A_PART = BIG_BM * BIG_LDH, B_PART = BN * BIG_LDH;
+    constexpr int BN = 64 * NT, BM = 64 * MT;
+    constexpr int A_PART = BM * BIG_LDH, B_PART = BN * BIG_LDH;
     __shared__ __attribute__((aligned(16))) __bf16 smem_h[3 * A_PART + 3 * B_PART];      // NT = 2: 46,080 B
     static_assert(sizeof(__bf16) * (3 * A_PART + 3 * B_PART) >= sizeof(float) * BIG_BM * (BN + 4), "epilogue tile");
-    __bf16 (*sA)[BIG_BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BM][BIG_LDH]>(smem_h);
+    __bf16 (*sA)[BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BM][BIG_LDH]>(smem_h);
     __bf16 (*sB)[BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BN][BIG_LDH]>(smem_h + 3 * A_PART);
 
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
@@ -593,17 +595,17 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
     const BigProblem& P = L.p[pi];
     const int n0 = (bx - P.tile_begin) * BN;
-    const int m0 = by * BIG_BM;
+    const int m0 = by * BM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
     const int K = P.K;
 
     const int srow = tid >> 3, skq = (tid & 7) * 4;
-    const float* xa[2];
+    const float* xa[2 * MT];
     const float* wb[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
+    for (int i = 0; i < 2 * MT; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
 #pragma unroll
     for (int i = 0; i < 2 * NT; ++i) wb[i] = P.W + (int64_t)min(n0 + srow + 32 * i, P.N - 1) * P.ldw + skq;
 
@@ -623,13 +625,15 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     const int nk = K / BIG_BK;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     // two register stages of global loads (stage = K-step parity): a K-step's operands are requested two steps ahead
-    float4 raA[2], raB[2], rbA[4], rbB[4];
+    float4 raA[2 * MT], raB[2 * MT], rbA[4], rbB[4];
     u32x4 rsA[6], rsB[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { rsA[i] = (u32x4)(0u); rsB[i] = (u32x4)(0u); }
     // row statistics of this thread's two staging rows: the 8 threads of a row fetch two parts each
     const bool ln = LNT && P.ln_g != nullptr;
-    float mu[2] = {0.f, 0.f}, rsd[2] = {1.f, 1.f};
+    float mu[2 * MT], rsd[2 * MT];
+#pragma unroll
+    for (int i = 0; i < 2 * MT; ++i) { mu[i] = 0.f; rsd[i] = 1.f; }
     float4 rg = make_float4(0.f, 0.f, 0.f, 0.f), re = rg;
     const float* gp = ln ? P.ln_g + skq : xa[0];
     const float* ep = ln ? P.ln_b + skq : xa[0];
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
         const float* st = ln ? P.stats_in : P.X;
         const int np = ln ? P.parts_in : 1, pw = ln ? P.pw_in : 1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 * MT; ++i) {
             const int64_t row = ln ? (int64_t)min(m0 + srow + 32 * i, L.M - 1) : 0;
             const int p0 = (tid & 7) * 2, p1 = p0 + 1;
             const float2 a = *reinterpret_cast<const float2*>(st + (row * np + min(p0, np - 1)) * 2);
@@ -661,8 +665,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 #define BIGS_LOAD(S, ks_)                                                   \
     {                                                                       \
         const int ko = min((ks_), nk - 1) * BIG_BK;                         \
-        ra##S[0] = *reinterpret_cast<const float4*>(xa[0] + ko);            \
-        ra##S[1] = *reinterpret_cast<const float4*>(xa[1] + ko);            \
+        _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i) ra##S[i] = *reinterpret_cast<const float4*>(xa[i] + ko); \
         if (PRESPLIT) {                                                     \
             rs##S[0] = *reinterpret_cast<const u32x4*>(ws0 + ko);           \
             rs##S[2] = *reinterpret_cast<const u32x4*>(ws0 + wplane + ko);  \
@@ -698,28 +701,27 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 #define BIGS_FRAG(S, part, row, half) (*reinterpret_cast<const bf16x8*>(&S[part][row][(half) * 16 + lh * 8]))
 #define BIGS_MMA(a, b, acc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     // smallest partial products first; the two accumulators alternate so that consecutive MFMAs are independent
-#define BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)               \
-    BIGS_MMA(am, b0m, acc0) BIGS_MMA(am, b1m, acc1) BIGS_MMA(al, b0h, acc0) BIGS_MMA(al, b1h, acc1) \
-    BIGS_MMA(ah, b0l, acc0) BIGS_MMA(ah, b1l, acc1) BIGS_MMA(am, b0h, acc0) BIGS_MMA(am, b1h, acc1) \
-    BIGS_MMA(ah, b0m, acc0) BIGS_MMA(ah, b1m, acc1) BIGS_MMA(ah, b0h, acc0) BIGS_MMA(ah, b1h, acc1)
-#define BIGS_SIX(ah, am, al, b0h, b0m, b0l)                                 \
-    BIGS_MMA(am, b0m, acc0) BIGS_MMA(al, b0h, acc0) BIGS_MMA(ah, b0l, acc0) \
-    BIGS_MMA(am, b0h, acc0) BIGS_MMA(ah, b0m, acc0) BIGS_MMA(ah, b0h, acc0)
+#define BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l, A0, A1)       \
+    BIGS_MMA(am, b0m, A0) BIGS_MMA(am, b1m, A1) BIGS_MMA(al, b0h, A0) BIGS_MMA(al, b1h, A1) \
+    BIGS_MMA(ah, b0l, A0) BIGS_MMA(ah, b1l, A1) BIGS_MMA(am, b0h, A0) BIGS_MMA(am, b1h, A1) \
+    BIGS_MMA(ah, b0m, A0) BIGS_MMA(ah, b1m, A1) BIGS_MMA(ah, b0h, A0) BIGS_MMA(ah, b1h, A1)
+#define BIGS_SIX(ah, am, al, b0h, b0m, b0l, A0)                             \
+    BIGS_MMA(am, b0m, A0) BIGS_MMA(al, b0h, A0) BIGS_MMA(ah, b0l, A0)       \
+    BIGS_MMA(am, b0h, A0) BIGS_MMA(ah, b0m, A0) BIGS_MMA(ah, b0h, A0)
     // one K-step from register stage S: LDS <- registers (normalised, split), then the requests for the step after next
     // (the LayerNorm parameters of the next step first: they are needed one step earlier than the stage's operands)
 #define BIGS_STEP(S, ks_)                                                   \
     {                                                                       \
         if ((ks_) > 0) __syncthreads();          /* every wave has read the previous stage */ \
         if (LNT && ln) {                                                    \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                 \
+            _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i) {            \
                 ra##S[i].x = big_silu((ra##S[i].x - mu[i]) * rsd[i] * rg.x + re.x); \
                 ra##S[i].y = big_silu((ra##S[i].y - mu[i]) * rsd[i] * rg.y + re.y); \
                 ra##S[i].z = big_silu((ra##S[i].z - mu[i]) * rsd[i] * rg.z + re.z); \
                 ra##S[i].w = big_silu((ra##S[i].w - mu[i]) * rsd[i] * rg.w + re.w); \
             }                                                               \
         }                                                                   \
-        BIGS_PUT(sA, srow, ra##S[0])                                        \
-        BIGS_PUT(sA, srow + 32, ra##S[1])                                   \
+        _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i) BIGS_PUT(sA, srow + 32 * i, ra##S[i]) \
         if (PRESPLIT) {                                                     \
             *reinterpret_cast<u32x4*>(wdst) = rs##S[0];                     \
             *reinterpret_cast<u32x4*>(wdst + B_PART) = rs##S[2];            \
@@ -748,9 +750,14 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
             if (NT == 2) {                                                  \
                 const bf16x8 b1h = BIGS_FRAG(sB, 0, wn * 64 + 32 + li, half), b1m = BIGS_FRAG(sB, 1, wn * 64 + 32 + li, half), \
                              b1l = BIGS_FRAG(sB, 2, wn * 64 + 32 + li, half); \
-                BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l)       \
+                BIGS_TWELVE(ah, am, al, b0h, b0m, b0l, b1h, b1m, b1l, acc0, acc1) \
+                if (MT == 2) {          /* the wave's second row tile: rows 64 + 32 wm ..., the same weight fragments */ \
+                    const bf16x8 ch = BIGS_FRAG(sA, 0, 64 + wm * 32 + li, half), cm = BIGS_FRAG(sA, 1, 64 + wm * 32 + li, half), \
+                                 cl = BIGS_FRAG(sA, 2, 64 + wm * 32 + li, half); \
+                    BIGS_TWELVE(ch, cm, cl, b0h, b0m, b0l, b1h, b1m, b1l, acc2, acc3) \
+                }                                                           \
             } else {                                                        \
-                BIGS_SIX(ah, am, al, b0h, b0m, b0l)                         \
+                BIGS_SIX(ah, am, al, b0h, b0m, b0l, acc0)                   \
             }                                                               \
         }                                                                   \
     }
@@ -758,9 +765,10 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     BIGS_LOADG(0)
     BIGS_LOAD(A, 0)
     BIGS_LOAD(B, 1)
-    f32x16 acc0, acc1;
+    static_assert(MT == 1 || NT == 2, "128-row tiles come with 128 columns");
+    f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
 
     int ks = 0;
     for (; ks + 1 < nk; ks += 2) {               // no branch inside: a branch around a step's loads makes every wait a full one
@@ -778,15 +786,18 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
 #undef BIGS_STEP
 
     // ---- epilogue (as k_linear_big): tile through LDS, + bias, + one-hot table rows, 16-byte stores
-    __syncthreads();
     float (*sC)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem_h);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 * NT + li] = acc0[i];
-        if (NT == 2) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
+    for (int pass = 0; pass < MT; ++pass) {      // 64 rows at a time: rows 64 pass + 32 wm ... of every wave
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 32 * NT + li] = pass == 0 ? acc0[i] : acc2[i];
+            if (NT == 2) sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = pass == 0 ? acc1[i] : acc3[i];
+        }
+        __syncthreads();
+        big_epilogue<BN>(L, P, sC, m0 + 64 * pass, n0, tid);
     }
-    __syncthreads();
-    big_epilogue<BN>(L, P, sC, m0, n0, tid);
 }
 
 // W (N, K) with row stride ldw -> bf16 images [planes][N][K]: h = bf16(w) and, with three planes,
