@@ -885,11 +885,13 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         for (int i = 0; i < np && presplit; ++i) presplit = (L.p[i].Ws = split_planes_of(specs[i], stream)) != nullptr;
     }
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
-    // split form with plenty of tiles: 128-row tiles (two row tiles per wave against the same weight fragments)
+    // bf16 and split forms with plenty of tiles: 128-row tiles (two row tiles per wave against the same weight fragments)
     static const int tall_min = [] { const char* e = std::getenv("DRM_SPLIT_TALL_MIN_TILES"); return e ? atoi(e) : 512; }();
-    const bool tall = precision == 2 && presplit && !narrow && (int64_t)tiles * ((M + 127) / 128) >= tall_min;
+    const bool tall = (precision == 1 || (precision == 2 && presplit)) && !narrow && (int64_t)tiles * ((M + 127) / 128) >= tall_min;
     const dim3 grid(tiles, tall ? (M + 127) / 128 : (M + BIG_BM - 1) / BIG_BM);
-    if (precision == 1 && presplit) k_linear_big_bf16<true><<<grid, dim3(256), 0, stream>>>(L);
+    if (precision == 1 && presplit && tall) k_linear_big_bf16<true, 2><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 1 && tall) k_linear_big_bf16<false, 2><<<grid, dim3(256), 0, stream>>>(L);
+    else if (precision == 1 && presplit) k_linear_big_bf16<true><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 1) k_linear_big_bf16<false><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 2) {
         bool any_ln = false;

@@ -450,11 +450,15 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BIG_LDH = 40;
 
-template <bool WH>
+// MT = 2: 128 x 128 tile, every wave two row tiles against the same weight fragments (8 LDS fragment reads per 8 MFMAs
+// instead of 6 per 4), for launches with enough tiles to fill the CUs that way.
+template <bool WH, int MT = 1>
 __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
-    __shared__ __attribute__((aligned(16))) float smem[BIG_BM * (BIG_BN + 4)];   // 64 x 132 floats >= the bf16 stages
-    __bf16 (*sA)[BIG_BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BM][BIG_LDH]>(smem);
-    __bf16 (*sB)[BIG_BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BN][BIG_LDH]>(reinterpret_cast<__bf16*>(smem) + 2 * BIG_BM * BIG_LDH);
+    constexpr int BM = 64 * MT;
+    constexpr int STAGE_WORDS = 2 * (BM + BIG_BN) * BIG_LDH / 2, TILE_WORDS = BIG_BM * (BIG_BN + 4);   // bf16 stages | 64-row epilogue tile
+    __shared__ __attribute__((aligned(16))) float smem[STAGE_WORDS > TILE_WORDS ? STAGE_WORDS : TILE_WORDS];
+    __bf16 (*sA)[BM][BIG_LDH] = reinterpret_cast<__bf16 (*)[BM][BIG_LDH]>(smem);
+    __bf16 (*sB)[BIG_BN][BIG_LDH] = reinterpret_cast<__bf16 (*)[BIG_BN][BIG_LDH]>(reinterpret_cast<__bf16*>(smem) + 2 * BM * BIG_LDH);
 
     const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
     int lin = blockIdx.y * nbx + blockIdx.x;
@@ -465,18 +469,18 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
     while (pi > 0 && bx < L.p[pi].tile_begin) --pi;
     const BigProblem& P = L.p[pi];
     const int n0 = (bx - P.tile_begin) * BIG_BN;
-    const int m0 = by * BIG_BM;
+    const int m0 = by * BM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
     const int K = P.K;
 
     const int srow = tid >> 3, skq = (tid & 7) * 4;
-    const float* xa[2];
+    const float* xa[2 * MT];
     const float* wb[4];
     const uint16_t* wh[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
+    for (int i = 0; i < 2 * MT; ++i) xa[i] = P.X + (int64_t)min(m0 + srow + 32 * i, L.M - 1) * P.ldx + skq;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t row = min(n0 + srow + 32 * i, P.N - 1);
@@ -485,11 +489,11 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
     }
 
     const int nk = K / BIG_BK;
-    f32x4 ra0[2], ra1[2], rb0[4], rb1[4];
+    f32x4 ra0[2 * MT], ra1[2 * MT], rb0[4], rb1[4];
     u32x2 rh0[4], rh1[4];
 #define BIGH_LOAD(S, ko)                                                                              \
     {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) ra##S[i] = *reinterpret_cast<const f32x4*>(xa[i] + (ko));  \
+        _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i) ra##S[i] = *reinterpret_cast<const f32x4*>(xa[i] + (ko));  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
             if (WH) rh##S[i] = *reinterpret_cast<const u32x2*>(wh[i] + (ko));                         \
             else rb##S[i] = *reinterpret_cast<const f32x4*>(wb[i] + (ko));                            \
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
     }
 #define BIGH_STORE(S, buf)                                                                            \
     {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) BIGH_PUT(&sA[buf][srow + 32 * i][skq], ra##S[i])  \
+        _Pragma("unroll") for (int i = 0; i < 2 * MT; ++i) BIGH_PUT(&sA[buf][srow + 32 * i][skq], ra##S[i])  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
             if (WH) *reinterpret_cast<u32x2*>(&sB[buf][srow + 32 * i][skq]) = rh##S[i];               \
             else BIGH_PUT(&sB[buf][srow + 32 * i][skq], rb##S[i])                                     \
@@ -521,14 +525,22 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb10, acc1, 0, 0, 0);                       \
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb01, acc0, 0, 0, 0);                       \
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb11, acc1, 0, 0, 0);                       \
+        if (MT == 2) {                      /* the wave's second row tile: rows 64 + 32 wm ... */        \
+            const bf16x8 fc0 = *reinterpret_cast<const bf16x8*>(&sA[buf][64 + wm * 32 + li][lh * 8]);       \
+            const bf16x8 fc1 = *reinterpret_cast<const bf16x8*>(&sA[buf][64 + wm * 32 + li][16 + lh * 8]);  \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc0, fb00, acc2, 0, 0, 0);                   \
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc0, fb10, acc3, 0, 0, 0);                   \
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc1, fb01, acc2, 0, 0, 0);                   \
+            acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc1, fb11, acc3, 0, 0, 0);                   \
+        }                                                                                               \
     }
     // loads past the last step re-read it (no branch around the loads)
     BIGH_LOAD(0, 0)
     BIGH_LOAD(1, (nk > 1 ? 1 : 0) * BIG_BK)
 
-    f32x16 acc0, acc1;
+    f32x16 acc0, acc1, acc2, acc3;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
 
     for (int ks = 0; ks < nk; ks += 2) {
         BIGH_STORE(0, 0)
@@ -548,15 +560,18 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
 #undef BIGH_STEP
 
     // ---- epilogue (as the fp32 form's path through LDS): + bias, + one-hot table rows, 16-byte stores
-    __syncthreads();
     float (*sC)[BIG_BN + 4] = reinterpret_cast<float (*)[BIG_BN + 4]>(smem);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = acc0[i];
-        sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = acc1[i];
+    for (int pass = 0; pass < MT; ++pass) {      // 64 rows at a time: rows 64 pass + 32 wm ... of every wave
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + li] = pass == 0 ? acc0[i] : acc2[i];
+            sC[wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh][wn * 64 + 32 + li] = pass == 0 ? acc1[i] : acc3[i];
+        }
+        __syncthreads();
+        big_epilogue<BIG_BN>(L, P, sC, m0 + 64 * pass, n0, tid);
     }
-    __syncthreads();
-    big_epilogue<BIG_BN>(L, P, sC, m0, n0, tid);
 }
 
 // ---- fp32 products on the bf16 matrix pipe: exact three-way split -----------------------------------

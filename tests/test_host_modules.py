@@ -143,16 +143,17 @@ def test_act_step_is_the_state_of_step(with_cont):
 
 
 def test_precision_names_resolve_to_library_codes(monkeypatch):
-    """``"f32"`` leaves the form of the fp32-accurate products to the engine: the split form from 256 trajectories on at the
-    default widths, fp32 matrix instructions for few trajectories and for wide models; explicit names are taken as given."""
+    """``"f32"`` leaves the form of the fp32-accurate products to the engine: the split form from 256 trajectories on
+    (any width), fp32 matrix instructions for fewer; explicit names are taken as given."""
     from dreamer_amd.imagine import resolve_precision
     monkeypatch.delenv("DRM_F32_MFMA", raising=False)
     assert resolve_precision("f32", 16, 512, 512) == 0
     assert resolve_precision("f32", 255, 512, 512) == 0
     assert resolve_precision("f32", 256, 512, 512) == 2
     assert resolve_precision("f32", 4096, 512, 512) == 2
-    assert resolve_precision("f32", 4096, 4096, 512) == 0          # wide recurrent state
-    assert resolve_precision("f32", 4096, 512, 1024) == 0          # wide hidden layers
+    assert resolve_precision("f32", 4096, 4096, 512) == 2          # wide recurrent state: the split form as well
+    assert resolve_precision("f32", 4096, 512, 1024) == 2          # wide hidden layers
+    assert resolve_precision("f32", 64, 4096, 512) == 0
     assert resolve_precision("f32_mfma", 4096, 512, 512) == 0
     assert resolve_precision("f32_split", 16, 512, 512) == 2
     assert resolve_precision("bf16", 16, 4096, 512) == 1

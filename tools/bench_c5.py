@@ -51,6 +51,24 @@ if ONLY in ("wm", "wm_bf16"):
     print(json.dumps(out))
     sys.exit(0)
 eng = ImagineEngine(wm, actor, critic)
+if ONLY == "split1024":       # the split form on the wide model: time and distance from the fp32 matrix instructions
+    Bi = 1024
+    h0 = torch.randn(Bi, D, generator=g).tanh().to(dev)
+    z0 = torch.nn.functional.one_hot(torch.randint(0, K, (Bi, L), generator=g), K).float().to(dev)
+    st = WorldModelState(h=h0, z=z0)
+    ea = torch.empty(15, Bi, A, device=dev).exponential_(); ez = torch.empty(15, Bi, L, K, device=dev).exponential_()
+    res = {}
+    for prec in ("f32_mfma", "f32_split"):
+        o = eng.run(st, 15, 0.997, 0.95, repack=False, precision=prec, noise={"a": ea, "z": ez})
+        res[prec] = {k: v.clone() for k, v in o.items() if torch.is_tensor(v)}
+        ms = timeit(lambda: eng.run(st, 15, 0.997, 0.95, repack=False, persistent=True, precision=prec), 5)
+        print(prec, "B=1024: %.2f ms per block" % ms, flush=True)
+    same = (res["f32_mfma"]["actions"] == res["f32_split"]["actions"]).all(dim=1)
+    print("trajectories with identical actions: %d of %d" % (int(same.sum()), Bi))
+    for k in ("h", "lam_returns", "values", "rewards"):
+        a, b = res["f32_mfma"][k][same], res["f32_split"][k][same]
+        print(k, "max |diff| on those: %.3e (scale %.3e)" % (float((a - b).abs().max()), float(a.abs().max())))
+    sys.exit(0)
 for Bi in ((16,) if ONLY == "imagine16" else (16, 1024)):
     h0 = torch.randn(Bi, D, generator=g).tanh().to(dev)
     z0 = torch.nn.functional.one_hot(torch.randint(0, K, (Bi, L), generator=g), K).float().to(dev)
