@@ -103,6 +103,7 @@ SIGNATURES = {
     "drm_ln_silu_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_void_p]),
     "drm_ln_silu_slices": (C.c_int32, [C.c_int64, C.c_int32]),
+    "drm_ln_silu_sums_floats": (C.c_size_t, [C.c_int64, C.c_int32]),
     "drm_ln_silu_backward": (C.c_int, [C.c_void_p] * 8 + [C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p]),
     "drm_seq_gather": (C.c_int, [C.POINTER(drm_ring), C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 6),
@@ -299,7 +300,7 @@ def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None, want_dx_
     dx = torch.empty_like(x)
     rows = 2 if (channel_bias is None and not want_dx_sum) else 3
     part = torch.empty((slices, rows, E), dtype=torch.float32, device=x.device)
-    sums = None if rows == 2 else torch.empty(2 * N, dtype=torch.float32, device=x.device)
+    sums = None if rows == 2 else torch.empty(lib().drm_ln_silu_sums_floats(N, E), dtype=torch.float32, device=x.device)
     hw = x.shape[2] * x.shape[3] if cl else (0 if channel_bias is None else E // channel_bias.numel())
     check(lib().drm_ln_silu_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, ptr(channel_bias), hw, int(cl),

@@ -469,7 +469,8 @@ int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_bwd_io* io,
  * channel_bias (optional, C = E / hw floats, hw = H*W a multiple of 4): the bias of the convolution that
  * produced x (nn.Conv2d / nn.ConvTranspose2d bias of the same stage) is added on the way in, i.e. the
  * block computes SiLU(LayerNorm(x + b[c])) and the convolution runs without its bias pass.  Backward then
- * needs sample_sums (2N floats, scratch) and writes param_partials (slices, 3, E); the third row summed
+ * needs sample_sums (drm_ln_silu_sums_floats(N, E) floats, scratch: 2N, and for many long samples the per-wave sums
+ * of the pass that walks the samples) and writes param_partials (slices, 3, E); the third row summed
  * over slices and over the hw positions of a channel is d b[c].  sample_sums without a channel bias
  * also selects the three-row form: the third row summed over slices is sum_n dx[n, e], the bias
  * gradient of a Linear in front of nn.LayerNorm(E) + nn.SiLU (the MLP blocks of lib/world_model.py:153-160).
@@ -480,6 +481,7 @@ int drm_ln_silu_forward(const float* x, const float* gamma, const float* beta, f
                         int64_t N, int32_t E, float eps, const float* channel_bias, int32_t hw, int32_t channels_last,
                         drm_stream_t stream);
 int32_t drm_ln_silu_slices(int64_t N, int32_t E);
+size_t drm_ln_silu_sums_floats(int64_t N, int32_t E);
 int drm_ln_silu_backward(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                          const float* rstd, float* dx, float* param_partials, int64_t N, int32_t E,
                          const float* channel_bias, int32_t hw, int32_t channels_last, float* sample_sums,

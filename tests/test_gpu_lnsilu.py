@@ -27,9 +27,11 @@ def test_matches_torch_layer_norm_silu(N, shape):
     assert rel(hw, gw) < 1e-5 and rel(hb, gb) < 1e-5
 
 
-@pytest.mark.parametrize("N,C,HW", [(64, 32, (32, 32)), (9, 8, (4, 4)), (130, 16, (8, 8)), (3, 4, (2, 2))])
+@pytest.mark.parametrize("N,C,HW", [(64, 32, (32, 32)), (9, 8, (4, 4)), (130, 16, (8, 8)), (3, 4, (2, 2)),
+                                    (261, 32, (16, 16)), (300, 256, (4, 4)), (257, 8, (64, 64))])
 def test_channel_bias_variant_matches_bias_add_then_layer_norm_silu(N, C, HW):
-    """SiLU(LayerNorm(x + b[c])) with the producing convolution's bias folded into the kernels, and its gradient."""
+    """SiLU(LayerNorm(x + b[c])) with the producing convolution's bias folded into the kernels, and its gradient
+    (the last three cases: many long samples, which take the passes that walk the samples)."""
     g = torch.Generator().manual_seed(N + C)
     shape = (C, *HW)
     x = (torch.randn(N, *shape, generator=g) * 1.3).to(DEV).requires_grad_(True)
@@ -86,7 +88,8 @@ def test_fused_mlp_block_matches_linear_layer_norm_silu(rows, k, width):
 
 
 @pytest.mark.parametrize("N,C,HW,with_cb", [(64, 32, (32, 32), True), (9, 8, (4, 4), True), (130, 16, (8, 8), False), (3, 4, (2, 3), True),
-                                            (5, 256, (4, 4), False)])
+                                            (5, 256, (4, 4), False), (261, 32, (16, 16), True), (300, 256, (4, 4), True),
+                                            (1024, 64, (16, 16), True), (259, 128, (8, 8), False)])
 def test_channels_last_samples_match_torch(N, C, HW, with_cb):
     """The same block on channels-last activations (parameters stay in (C, H, W) order)."""
     g = torch.Generator().manual_seed(N + C)

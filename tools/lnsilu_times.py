@@ -32,6 +32,10 @@ for c, hw in ((32, 32), (64, 16), (128, 8), (256, 4)):
         tf = t(lambda: N.ln_silu_forward(x, g, b, 1e-5, cb))
         tb = t(lambda: N.ln_silu_backward(x, dy, g, b, mean, rstd, cb))
         mb = x.numel() * 4 / 1e6
+        if os.environ.get("LN_REFERENCE_OPS") and not cl:
+            yy = torch.empty_like(x)
+            print(f"    same size: copy {t(lambda: yy.copy_(x)):6.1f} us, silu {t(lambda: torch.nn.functional.silu(x)):6.1f} us, "
+                  f"x * y {t(lambda: torch.mul(x, dy)):6.1f} us")
         if os.environ.get("LN_NO_BIAS"):
             tf0 = t(lambda: N.ln_silu_forward(x, g, b, 1e-5, None))
             print(f"    without the channel bias: forward {tf0:6.1f} us")
