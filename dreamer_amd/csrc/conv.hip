@@ -347,8 +347,9 @@ extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* bi
     ConvArgs g{nullptr, small, kernel, big_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-    if (cb <= 32 && std::getenv("DRM_CONV_NO_TALL_TILE") == nullptr)   // outputs of 32 columns: waves 4 x 1 over a 256 x 32 tile instead of half-empty 64-column tiles
-        k_conv_gemm<CONV_UP, 2, 1, 1><<<dim3(1, (unsigned)((pixels + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    if (cb <= 32 && std::getenv("DRM_CONV_NO_TALL_TILE") == nullptr)   // outputs of 32 columns: waves 4 x 1 over a 128 x 32 tile instead of half-empty 64-column tiles
+        // (a 256 x 32 tile moves fewer operand bytes per product but its 92 KB of LDS leave one workgroup per CU: 312 against 256 us)
+        k_conv_gemm<CONV_UP, 1, 1, 1><<<dim3(1, (unsigned)((pixels + 127) / 128), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
     else if (conv_wide_tiles(cb))
         k_conv_gemm<CONV_UP, 2, 2><<<dim3(cb / 128, (unsigned)((pixels + 127) / 128), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
     else
