@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from .actor import state_features
 from .utils import symexp, symlog
-from .world_model import WorldModelState, _norm_act_mlp
+from .world_model import WorldModelState, _Linear, _norm_act_mlp
 
 
 class Critic(nn.Module):
@@ -22,7 +22,7 @@ class Critic(nn.Module):
         self.bucket_delta = (bucket_max - bucket_min) / (num_buckets - 1)
         self.register_buffer("buckets", torch.linspace(bucket_min, bucket_max, num_buckets))
         self.mlp = _norm_act_mlp(state_size, mlp_hidden_units, mlp_layers)
-        self.head = nn.Linear(mlp_hidden_units, num_buckets)
+        self.head = _Linear(mlp_hidden_units, num_buckets)   # nn.Linear; its 240-row evaluations on the library's product
         nn.init.zeros_(self.head.weight)
         nn.init.zeros_(self.head.bias)
         self.ema_decay, self.ema_regularizer = ema_decay, ema_regularizer

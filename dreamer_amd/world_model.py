@@ -38,10 +38,17 @@ class WorldModelState:
 NATIVE_GEMM_MIN_ROWS = int(os.environ.get("DRM_NATIVE_GEMM_MIN_ROWS", "256"))
 
 
+def _odd_width_few_rows(rows: int, out_features: int) -> bool:
+    """A few hundred rows into a width that is no multiple of 64 (the critic's 255 buckets at the 240 imagined states):
+    the backend's choice for that shape is a 256 x 240 macro-tile, six workgroups on the whole device, 127 us for
+    63 MFLOP -- the library's kernel takes such a product even below ``NATIVE_GEMM_MIN_ROWS``."""
+    return rows >= 128 and out_features % 64 != 0
+
+
 def _mm_forward(x, w, b):
     """x @ w.T + b for a Linear weight w (out, in)."""
     from . import _native as N
-    if x.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(x, w, False, False):
+    if (x.shape[0] >= NATIVE_GEMM_MIN_ROWS or _odd_width_few_rows(x.shape[0], w.shape[0])) and N.gemm_ok(x, w, False, False):
         return N.gemm(x, w, False, False, bias=b)
     return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
 
@@ -83,7 +90,8 @@ class _LinearFn(torch.autograd.Function):
 
 def _linear(x, w, b=None):
     """F.linear for 2-D inputs; many-row fp32 inputs on a HIP device take the library's products."""
-    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= NATIVE_GEMM_MIN_ROWS:
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and (
+            x.shape[0] >= NATIVE_GEMM_MIN_ROWS or _odd_width_few_rows(x.shape[0], w.shape[0])):
         return _LinearFn.apply(x if x.stride(1) == 1 else x.contiguous(), w, b)
     return F.linear(x, w, b)
 
