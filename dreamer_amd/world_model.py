@@ -38,6 +38,32 @@ class WorldModelState:
 NATIVE_GEMM_MIN_ROWS = int(os.environ.get("DRM_NATIVE_GEMM_MIN_ROWS", "256"))
 
 
+# Set by WorldModel.loss for a wide model whose scan runs with bf16 matrix inputs: the batched Linear products large enough
+# for the bf16 large-row kernel (output tiles to fill the device, a reduction of 256 or more) then take bf16 matrix inputs
+# with fp32 accumulation as well.  Read when a layer's forward runs and remembered for its backward.
+_BF16_PRODUCTS = False
+
+
+class _bf16_products:
+    """Context manager for ``_BF16_PRODUCTS``."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _BF16_PRODUCTS
+        self.before, _BF16_PRODUCTS = _BF16_PRODUCTS, self.on
+
+    def __exit__(self, *exc):
+        global _BF16_PRODUCTS
+        _BF16_PRODUCTS = self.before
+
+
+def _bf16_product_ok(rows: int, cols: int, k: int) -> bool:
+    """Output of rows x cols from a reduction of length k: enough 64 x 128 tiles for the device, k a multiple of 32."""
+    return rows >= 256 and k >= 256 and k % 32 == 0 and (rows // 64) * (cols // 128) >= 256
+
+
 def _odd_width_few_rows(rows: int, out_features: int) -> bool:
     """A few hundred rows into a width that is no multiple of 64 (the critic's 255 buckets at the 240 imagined states):
     the backend's choice for that shape is a 256 x 240 macro-tile, six workgroups on the whole device, 127 us for
@@ -45,25 +71,31 @@ def _odd_width_few_rows(rows: int, out_features: int) -> bool:
     return rows >= 128 and out_features % 64 != 0
 
 
-def _mm_forward(x, w, b):
+def _mm_forward(x, w, b, bf16=False):
     """x @ w.T + b for a Linear weight w (out, in)."""
     from . import _native as N
+    if bf16 and x.is_cuda and x.stride(1) == 1 and _bf16_product_ok(x.shape[0], w.shape[0], x.shape[1]):
+        return N.fused_linear(x, w, b, bf16=True)
     if (x.shape[0] >= NATIVE_GEMM_MIN_ROWS or _odd_width_few_rows(x.shape[0], w.shape[0])) and N.gemm_ok(x, w, False, False):
         return N.gemm(x, w, False, False, bias=b)
     return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
 
 
-def _mm_dgrad(dy, w):
+def _mm_dgrad(dy, w, bf16=False):
     """dy @ w: the input gradient of a Linear with weight w (out, in)."""
     from . import _native as N
+    if bf16 and dy.is_cuda and _bf16_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
+        return N.fused_linear(dy, w.t().contiguous(), bf16=True)       # the reduction runs over w's rows: transposed once
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, w, False, True):
         return N.gemm(dy, w, False, True)
     return dy @ w
 
 
-def _mm_wgrad(dy, x):
+def _mm_wgrad(dy, x, bf16=False):
     """dy.T @ x: the weight gradient of a Linear, a sum over the rows."""
     from . import _native as N
+    if bf16 and dy.is_cuda and _bf16_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
+        return N.fused_linear(dy.t().contiguous(), x.t().contiguous(), bf16=True)   # the sum over the rows along memory
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, x, True, True):
         return N.gemm(dy, x, True, True)
     return dy.t() @ x
@@ -76,14 +108,15 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return _mm_forward(x, w, b)
+        ctx.bf16 = _BF16_PRODUCTS
+        return _mm_forward(x, w, b, ctx.bf16)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = _mm_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = _mm_wgrad(dy, x) if ctx.needs_input_grad[1] else None
+        dx = _mm_dgrad(dy, w, ctx.bf16) if ctx.needs_input_grad[0] else None
+        dw = _mm_wgrad(dy, x, ctx.bf16) if ctx.needs_input_grad[1] else None
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -111,7 +144,8 @@ class _LinearNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, eps):
         from . import _native as N
-        pre = _mm_forward(x, w, b)
+        ctx.bf16 = _BF16_PRODUCTS
+        pre = _mm_forward(x, w, b, ctx.bf16)
         y, mean, rstd = N.ln_silu_forward(pre, gamma, beta, eps)
         ctx.save_for_backward(x, w, pre, gamma, beta, mean, rstd)
         return y
@@ -121,8 +155,8 @@ class _LinearNormActFn(torch.autograd.Function):
         from . import _native as N
         x, w, pre, gamma, beta, mean, rstd = ctx.saved_tensors
         dpre, dparams, db = N.ln_silu_backward(pre, dy.contiguous(), gamma, beta, mean, rstd, want_dx_sum=True)
-        dx = _mm_dgrad(dpre, w) if ctx.needs_input_grad[0] else None
-        return dx, _mm_wgrad(dpre, x), db, dparams[0], dparams[1], None
+        dx = _mm_dgrad(dpre, w, ctx.bf16) if ctx.needs_input_grad[0] else None
+        return dx, _mm_wgrad(dpre, x, ctx.bf16), db, dparams[0], dparams[1], None
 
 
 class _MLP(nn.Sequential):
@@ -666,6 +700,13 @@ class WorldModel(nn.Module):
         L, K = self.num_latents, self.classes_per_latent
         h, z, post, last = self.observe(obs, actions, continues, init_state, noise)
         hf, zf = h.reshape(B * T, -1), z.reshape(B * T, L, K)
+        # a wide model whose scan takes bf16 matrix inputs: the large batched Linear products of the heads as well
+        with _bf16_products(getattr(self, "observe_precision", "f32") == "bf16" and self.hidden_size > 512):
+            return self._loss_from_states(obs, rewards, continues, h, z, post, last, hf, zf)
+
+    def _loss_from_states(self, obs, rewards, continues, h, z, post, last, hf, zf):
+        B, T = obs.shape[:2]
+        L, K = self.num_latents, self.classes_per_latent
         prior = self.dyn(hf)
         postf = post.reshape(B * T, L, K)
         x_true, x_hat = obs.reshape(B * T, *obs.shape[2:]), self.dec(hf, zf)
