@@ -169,7 +169,12 @@ class ObserveScanFn(torch.autograd.Function):
         z_in = F.one_hot(zidx_in.reshape(B * T, L).long(), K).to(h.dtype).reshape(B * T, LK)
         a_vec = a_emb[a2] * c2
         # the two products over the recurrent width: with bf16 matrix inputs when the scan ran that way
-        wide_wgrad = _wgrad_bf16 if eng.precision == 1 and _wgrad_bf16_ok(gi2, D) else _mm_wgrad
+        # (otherwise, when large enough, in the split form: fp32 accuracy on the bf16 matrix pipe)
+        from . import world_model as W
+        if eng.precision == 1 and _wgrad_bf16_ok(gi2, D):
+            wide_wgrad = _wgrad_bf16
+        else:
+            wide_wgrad = lambda dy_, x_: _mm_wgrad(dy_, x_, "f32" if W._PRODUCT_FORM == "f32" else "split")
         g_w_ih = wide_wgrad(gi2, x.reshape(B * T, D))
         g_w_hh = wide_wgrad(gh2, h_in.reshape(B * T, D))
         g_lin_w = torch.cat([_mm_wgrad(dx2, z_in), _mm_wgrad(dx2, a_vec)], dim=1)

@@ -38,25 +38,34 @@ class WorldModelState:
 NATIVE_GEMM_MIN_ROWS = int(os.environ.get("DRM_NATIVE_GEMM_MIN_ROWS", "256"))
 
 
-# Set by WorldModel.loss for a wide model whose scan runs with bf16 matrix inputs: the batched Linear products large enough
-# for the bf16 large-row kernel (output tiles to fill the device, a reduction of 256 or more) then take bf16 matrix inputs
-# with fp32 accumulation as well.  Read when a layer's forward runs and remembered for its backward.
-_BF16_PRODUCTS = False
+# Form of the batched Linear products that are large enough for the large-row kernels (output tiles to fill the device, a
+# reduction of 256 or more): "split" = fp32 accuracy from an exact three-way bf16 split of both operands on the bf16 matrix
+# pipe (1.25-1.35x the fp32 matrix instructions on these shapes, and a little closer to the fp64 result), "bf16" = bf16
+# matrix inputs with fp32 accumulation (set by WorldModel.loss for a wide model whose scan runs that way), "f32" = the fp32
+# kernel for everything (DRM_NO_SPLIT_PRODUCTS=1).  Read when a layer's forward runs and remembered for its backward.
+_PRODUCT_FORM = "f32" if os.environ.get("DRM_NO_SPLIT_PRODUCTS", "0") == "1" else "split"
 
 
 class _bf16_products:
-    """Context manager for ``_BF16_PRODUCTS``."""
+    """Context manager: the large products take bf16 matrix inputs inside."""
 
     def __init__(self, on: bool):
         self.on = bool(on)
 
     def __enter__(self):
-        global _BF16_PRODUCTS
-        self.before, _BF16_PRODUCTS = _BF16_PRODUCTS, self.on
+        global _PRODUCT_FORM
+        self.before = _PRODUCT_FORM
+        if self.on:
+            _PRODUCT_FORM = "bf16"
 
     def __exit__(self, *exc):
-        global _BF16_PRODUCTS
-        _BF16_PRODUCTS = self.before
+        global _PRODUCT_FORM
+        _PRODUCT_FORM = self.before
+
+
+def _large_product(form: str, x, w, b=None):
+    from . import _native as N
+    return N.fused_linear(x, w, b, bf16=form == "bf16", split=form == "split")
 
 
 def _bf16_product_ok(rows: int, cols: int, k: int) -> bool:
@@ -71,31 +80,31 @@ def _odd_width_few_rows(rows: int, out_features: int) -> bool:
     return rows >= 128 and out_features % 64 != 0
 
 
-def _mm_forward(x, w, b, bf16=False):
+def _mm_forward(x, w, b, form="f32"):
     """x @ w.T + b for a Linear weight w (out, in)."""
     from . import _native as N
-    if bf16 and x.is_cuda and x.stride(1) == 1 and _bf16_product_ok(x.shape[0], w.shape[0], x.shape[1]):
-        return N.fused_linear(x, w, b, bf16=True)
+    if form != "f32" and x.is_cuda and x.stride(1) == 1 and _bf16_product_ok(x.shape[0], w.shape[0], x.shape[1]):
+        return _large_product(form, x, w, b)
     if (x.shape[0] >= NATIVE_GEMM_MIN_ROWS or _odd_width_few_rows(x.shape[0], w.shape[0])) and N.gemm_ok(x, w, False, False):
         return N.gemm(x, w, False, False, bias=b)
     return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
 
 
-def _mm_dgrad(dy, w, bf16=False):
+def _mm_dgrad(dy, w, form="f32"):
     """dy @ w: the input gradient of a Linear with weight w (out, in)."""
     from . import _native as N
-    if bf16 and dy.is_cuda and _bf16_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
-        return N.fused_linear(dy, w.t().contiguous(), bf16=True)       # the reduction runs over w's rows: transposed once
+    if form != "f32" and dy.is_cuda and _bf16_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
+        return _large_product(form, dy, w.t().contiguous())       # the reduction runs over w's rows: transposed once
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, w, False, True):
         return N.gemm(dy, w, False, True)
     return dy @ w
 
 
-def _mm_wgrad(dy, x, bf16=False):
+def _mm_wgrad(dy, x, form="f32"):
     """dy.T @ x: the weight gradient of a Linear, a sum over the rows."""
     from . import _native as N
-    if bf16 and dy.is_cuda and _bf16_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
-        return N.fused_linear(dy.t().contiguous(), x.t().contiguous(), bf16=True)   # the sum over the rows along memory
+    if form != "f32" and dy.is_cuda and _bf16_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
+        return _large_product(form, dy.t().contiguous(), x.t().contiguous())   # the sum over the rows along memory
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, x, True, True):
         return N.gemm(dy, x, True, True)
     return dy.t() @ x
@@ -108,15 +117,15 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        ctx.bf16 = _BF16_PRODUCTS
-        return _mm_forward(x, w, b, ctx.bf16)
+        ctx.form = _PRODUCT_FORM
+        return _mm_forward(x, w, b, ctx.form)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = _mm_dgrad(dy, w, ctx.bf16) if ctx.needs_input_grad[0] else None
-        dw = _mm_wgrad(dy, x, ctx.bf16) if ctx.needs_input_grad[1] else None
+        dx = _mm_dgrad(dy, w, ctx.form) if ctx.needs_input_grad[0] else None
+        dw = _mm_wgrad(dy, x, ctx.form) if ctx.needs_input_grad[1] else None
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -144,8 +153,8 @@ class _LinearNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, eps):
         from . import _native as N
-        ctx.bf16 = _BF16_PRODUCTS
-        pre = _mm_forward(x, w, b, ctx.bf16)
+        ctx.form = _PRODUCT_FORM
+        pre = _mm_forward(x, w, b, ctx.form)
         y, mean, rstd = N.ln_silu_forward(pre, gamma, beta, eps)
         ctx.save_for_backward(x, w, pre, gamma, beta, mean, rstd)
         return y
@@ -155,8 +164,8 @@ class _LinearNormActFn(torch.autograd.Function):
         from . import _native as N
         x, w, pre, gamma, beta, mean, rstd = ctx.saved_tensors
         dpre, dparams, db = N.ln_silu_backward(pre, dy.contiguous(), gamma, beta, mean, rstd, want_dx_sum=True)
-        dx = _mm_dgrad(dpre, w, ctx.bf16) if ctx.needs_input_grad[0] else None
-        return dx, _mm_wgrad(dpre, x, ctx.bf16), db, dparams[0], dparams[1], None
+        dx = _mm_dgrad(dpre, w, ctx.form) if ctx.needs_input_grad[0] else None
+        return dx, _mm_wgrad(dpre, x, ctx.form), db, dparams[0], dparams[1], None
 
 
 class _MLP(nn.Sequential):
