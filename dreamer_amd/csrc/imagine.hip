@@ -887,7 +887,7 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
     ProfScope prof(PC_LINEAR_BIG, stream, fl, by);
     // bf16 and split forms with plenty of tiles: 128-row tiles (two row tiles per wave against the same weight fragments)
     static const int tall_min = [] { const char* e = std::getenv("DRM_SPLIT_TALL_MIN_TILES"); return e ? atoi(e) : 512; }();
-    const bool tall = (precision == 1 || (precision == 2 && presplit)) && !narrow && (int64_t)tiles * ((M + 127) / 128) >= tall_min;
+    const bool tall = (precision == 1 || precision == 2) && !narrow && (int64_t)tiles * ((M + 127) / 128) >= tall_min;
     const dim3 grid(tiles, tall ? (M + 127) / 128 : (M + BIG_BM - 1) / BIG_BM);
     if (precision == 1 && presplit && tall) k_linear_big_bf16<true, 2><<<grid, dim3(256), 0, stream>>>(L);
     else if (precision == 1 && tall) k_linear_big_bf16<false, 2><<<grid, dim3(256), 0, stream>>>(L);
@@ -898,9 +898,12 @@ int launch_big(ProblemSpec* specs, int np, int M, const uint8_t* zidx, int64_t l
         for (int i = 0; i < np; ++i) any_ln = any_ln || specs[i].ln_g != nullptr;
 #define DRM_SPLIT(PRE, NTV) { if (any_ln) k_linear_big_split<PRE, NTV, true><<<grid, dim3(256), 0, stream>>>(L); \
                               else k_linear_big_split<PRE, NTV, false><<<grid, dim3(256), 0, stream>>>(L); }
-        if (tall) {
+        if (tall && presplit) {
             if (any_ln) k_linear_big_split<true, 2, true, 2><<<grid, dim3(256), 0, stream>>>(L);
             else k_linear_big_split<true, 2, false, 2><<<grid, dim3(256), 0, stream>>>(L);
+        } else if (tall) {
+            if (any_ln) k_linear_big_split<false, 2, true, 2><<<grid, dim3(256), 0, stream>>>(L);
+            else k_linear_big_split<false, 2, false, 2><<<grid, dim3(256), 0, stream>>>(L);
         } else if (presplit && narrow) DRM_SPLIT(true, 1) else if (presplit) DRM_SPLIT(true, 2) else if (narrow) DRM_SPLIT(false, 1) else DRM_SPLIT(false, 2)
 #undef DRM_SPLIT
     } else {
