@@ -52,7 +52,9 @@ def _recording(graph, stream=None):
     gc.collect()
     gc.disable()
     try:
-        with torch.cuda.graph(graph, stream=stream):
+        # thread-local error mode: runtime calls of other threads (a collective backend's watchdog polling its events)
+        # must not invalidate a recording they have no part in
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
             yield
     finally:
         if was_enabled:
