@@ -68,7 +68,7 @@ def _large_product(form: str, x, w, b=None):
     return N.fused_linear(x, w, b, bf16=form == "bf16", split=form == "split")
 
 
-def _bf16_product_ok(rows: int, cols: int, k: int) -> bool:
+def _large_product_ok(rows: int, cols: int, k: int) -> bool:
     """Output of rows x cols from a reduction of length k: enough 64 x 128 tiles for the device, k a multiple of 32."""
     return rows >= 256 and k >= 256 and k % 32 == 0 and (rows // 64) * (cols // 128) >= 256
 
@@ -83,7 +83,8 @@ def _odd_width_few_rows(rows: int, out_features: int) -> bool:
 def _mm_forward(x, w, b, form="f32"):
     """x @ w.T + b for a Linear weight w (out, in)."""
     from . import _native as N
-    if form != "f32" and x.is_cuda and x.stride(1) == 1 and _bf16_product_ok(x.shape[0], w.shape[0], x.shape[1]):
+    if (form != "f32" and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and w.stride(1) == 1
+            and _large_product_ok(x.shape[0], w.shape[0], x.shape[1])):
         return _large_product(form, x, w, b)
     if (x.shape[0] >= NATIVE_GEMM_MIN_ROWS or _odd_width_few_rows(x.shape[0], w.shape[0])) and N.gemm_ok(x, w, False, False):
         return N.gemm(x, w, False, False, bias=b)
@@ -93,7 +94,7 @@ def _mm_forward(x, w, b, form="f32"):
 def _mm_dgrad(dy, w, form="f32"):
     """dy @ w: the input gradient of a Linear with weight w (out, in)."""
     from . import _native as N
-    if form != "f32" and dy.is_cuda and _bf16_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
+    if form != "f32" and dy.is_cuda and dy.dtype == torch.float32 and dy.stride(1) == 1 and _large_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
         return _large_product(form, dy, w.t().contiguous())       # the reduction runs over w's rows: transposed once
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, w, False, True):
         return N.gemm(dy, w, False, True)
@@ -103,7 +104,7 @@ def _mm_dgrad(dy, w, form="f32"):
 def _mm_wgrad(dy, x, form="f32"):
     """dy.T @ x: the weight gradient of a Linear, a sum over the rows."""
     from . import _native as N
-    if form != "f32" and dy.is_cuda and _bf16_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
+    if form != "f32" and dy.is_cuda and dy.dtype == torch.float32 and _large_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
         return _large_product(form, dy.t().contiguous(), x.t().contiguous())   # the sum over the rows along memory
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, x, True, True):
         return N.gemm(dy, x, True, True)
