@@ -10,8 +10,13 @@ namespace drm {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
-int launch_check(const char* func, const char* file, int line) {
+int sync_check_mode() {
     static const int mode = [] { const char* e = std::getenv("DRM_SYNC_CHECK"); return e != nullptr ? atoi(e) : 0; }();
+    return mode;
+}
+
+int launch_check(const char* func, const char* file, int line) {
+    const int mode = sync_check_mode();
     const bool sync = mode != 0;
     hipError_t e = hipGetLastError();
     // mode 2: the launch site goes to stderr before the wait, so that a memory fault (which ends the process inside the

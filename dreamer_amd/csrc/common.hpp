@@ -34,6 +34,9 @@ void set_error(const std::string& msg);
 // failure is reported on stderr with the launch site, so an asynchronous memory fault names the kernel that caused it
 // (diagnostic mode: serialises everything); DRM_SYNC_CHECK=2 also prints every launch site before waiting for it.
 int launch_check(const char* func, const char* file, int line);
+// DRM_SYNC_CHECK (0: off).  A synchronising launch check cannot run inside a recording: the entry points that record
+// graphs launch directly while it is on.
+int sync_check_mode();
 #define DRM_LAUNCH_CHECK()                                                       \
     do {                                                                         \
         if (int _rc = ::drm::launch_check(__func__, __FILE__, __LINE__)) return _rc; \

@@ -1629,7 +1629,7 @@ extern "C" int drm_graph_cache_clear(void) {
 
 extern "C" int drm_imagine_block_f32(const drm_imagine_weights* w, const drm_imagine_io* io, drm_stream_t stream) {
     DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
-    if (!io->use_graph || prof_on()) return imagine_enqueue(w, io, stream);
+    if (!io->use_graph || prof_on() || sync_check_mode() != 0) return imagine_enqueue(w, io, stream);
     hipStream_t s = (hipStream_t)stream;
     int dev = 0;
     DRM_HIP(hipGetDevice(&dev));

@@ -715,7 +715,7 @@ extern "C" size_t drm_observe_workspace_bytes(const drm_dims* dims, int32_t B, i
 extern "C" int drm_observe_forward_f32(const drm_observe_weights* w, const drm_observe_io* io, drm_stream_t stream) {
     DRM_REQUIRE(w && io, DRM_EINVAL, "null pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (!io->use_graph || prof_on()) return observe_enqueue(w, io, s);
+    if (!io->use_graph || prof_on() || sync_check_mode() != 0) return observe_enqueue(w, io, s);
     int dev = 0;
     DRM_HIP(hipGetDevice(&dev));
     std::vector<uint8_t> key(sizeof(*w) + sizeof(*io) + sizeof(int));

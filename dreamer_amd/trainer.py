@@ -43,6 +43,11 @@ def _adam(params, lr, eps, capturable=False):
     return torch.optim.Adam(params, lr=lr, eps=eps, fused=params[0].is_cuda, capturable=capturable and params[0].is_cuda)
 
 
+def _sync_check() -> bool:
+    """DRM_SYNC_CHECK: the library synchronises after every launch, which no recording allows; updates stay eager then."""
+    return os.environ.get("DRM_SYNC_CHECK", "0") not in ("", "0")
+
+
 @contextlib.contextmanager
 def _recording(graph, stream=None):
     """torch.cuda.graph(graph) with the cyclic garbage collector held off: a collection that runs while
@@ -160,7 +165,7 @@ class ActingPolicy:
         self.wm, self.actor = world_model, actor
         self.device = torch.device(device)
         on_gpu = self.device.type == "cuda"
-        self.use_graph = on_gpu and os.environ.get("DRM_NO_ACT_GRAPH", "0") != "1"
+        self.use_graph = on_gpu and os.environ.get("DRM_NO_ACT_GRAPH", "0") != "1" and not _sync_check()
         self.frame = torch.zeros(1, *obs_shape, dtype=torch.uint8, device=self.device)
         self.stage = torch.zeros(1, *obs_shape, dtype=torch.uint8, pin_memory=True) if on_gpu else None
         self.h = torch.zeros(1, world_model.hidden_size, device=self.device)
@@ -265,7 +270,7 @@ class Learner:
             self.optim_actor = _adam(self.actor.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
             self.optim_critic = _adam(self.critic.parameters(), cfg.actor_critic_lr, cfg.actor_critic_adam_eps, capturable=on_gpu)
         # actor / critic updates replayed from HIP graphs after a few eager ones (DRM_NO_UPDATE_GRAPHS=1: always eager)
-        self.graph_updates = on_gpu and os.environ.get("DRM_NO_UPDATE_GRAPHS", "0") != "1"
+        self.graph_updates = on_gpu and os.environ.get("DRM_NO_UPDATE_GRAPHS", "0") != "1" and not _sync_check()
         self.eager_updates = 0
         self._wm_graph = _GraphedUpdate(None, self.g_wm, cfg.world_model_grad_clip, self.optim_world_model)
         # Every update runs on one stream of the learner's own (DRM_ONE_STREAM=0: on the caller's): the recordings below
