@@ -298,18 +298,286 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ p
     }
 }
 
+// ---- the same three products on the bf16 matrix pipe: exact three-way split of both operands ------------------------
+// Every fp32 operand value is split exactly into three bf16 parts (a = h + m + l: 8 + 8 + 8 mantissa bits) on its way
+// into LDS and a*b is accumulated in fp32 from the six partial products above 2^-24 |a b|, as in the large Linear
+// products: results agree with the fp32 form to fp32 rounding while the matrix pipe runs v_mfma_f32_32x32x16_bf16,
+// a third of the pipe time of v_mfma_f32_32x32x2_f32 for the same reduction range.
+//
+// LDS image of an operand tile of R rows x 32 k, one per part: [k / 8][slot][8 k] (16 bytes per slot and k group; a
+// lane's MFMA fragment is one 16-byte read), k-group stride 16 R + 128 bytes so that the four k groups a staging wave
+// writes fall on the two halves of the banks.  Operands whose reduction index is contiguous in memory are staged as in
+// the fp32 form (slot = row).  The others (reduction index = pixel or input channel, rows contiguous) are loaded as
+// 4 k x 4 row blocks per thread -- rows 4 g ... 4 g + 3 of k quad q, 16 bytes per k -- and transposed in registers; row
+// 4 g + e goes to slot e R/4 + g, which makes the 8-byte LDS writes of a wave contiguous.  Which tile row an MFMA row
+// stands for is undone on the way out, in the epilogue's tile through LDS.
+typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cv_bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int cvs_kgs(int rows) { return rows * 8 + 64; }       // bf16 elements between k groups
+
+__device__ __forceinline__ void cvs_put(__bf16* dst, int part_stride, float f0, float f1, float f2, float f3) {
+    const float f[4] = {f0, f1, f2, f3};
+    cv_bf16x4 h, m, l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        h[c] = (__bf16)f[c];
+        const float r1 = f[c] - (float)h[c];
+        m[c] = (__bf16)r1;
+        l[c] = (__bf16)(r1 - (float)m[c]);
+    }
+    *reinterpret_cast<cv_bf16x4*>(dst) = h;
+    *reinterpret_cast<cv_bf16x4*>(dst + part_stride) = m;
+    *reinterpret_cast<cv_bf16x4*>(dst + 2 * part_stride) = l;
+}
+
+template <int MODE, int MT, int NT, int WN = 2>
+__global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
+    constexpr int BM = 32 * MT * (4 / WN), BN = 32 * NT * WN;
+    constexpr bool A_ROWK = MODE != CONV_WGRAD;     // DOWN / UP: A is [row][k]; WGRAD: A is [k][row]
+    constexpr bool B_ROWK = MODE == CONV_DOWN;      // DOWN: B = Q rows [j][k]; UP / WGRAD: [k][col]
+    constexpr int A_KGS = cvs_kgs(BM), B_KGS = cvs_kgs(BN), A_PART = 4 * A_KGS, B_PART = 4 * B_KGS;
+    constexpr int STAGE_BYTES = 2 * 3 * (A_PART + B_PART), TILE_BYTES = 4 * BM * (BN + 4);
+    constexpr int NVB = B_ROWK ? BN / 32 : 4;       // f32x4 per thread and K-step of the B tile (A: 4 either way)
+    static_assert(A_ROWK ? BM == 128 : true, "pixel-row tiles are 128 rows");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
+    __bf16* const sA = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* const sB = sA + 3 * A_PART;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = WN == 2 ? (wave & 1) : wave, wn = WN == 2 ? (wave >> 1) : 0, li = lane & 31, lh = lane >> 5;
+    const int Hs = G.Hs, Ws = G.Ws, cs = G.cs, cb = G.cb, Hb = 2 * Hs, Wb = 2 * Ws;
+    const int pixels = G.NI * Hs * Ws;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // [row][k] staging: rows (tid >> 3) + 32 i, k offset (tid & 7) * 4
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    // [k][row] staging: row group and k quad of this thread's 4 x 4 block (threads past the tile's 8 k quads stage nothing)
+    const int a_rg = tid % (BM / 4), a_kq = tid / (BM / 4);
+    const int b_rg = tid % (BN / 4), b_kq = tid / (BN / 4);
+    const bool a_on = A_ROWK || a_kq < 8, b_on = B_ROWK || b_kq < 8;
+
+    int pn[4], pa[4], pb[4];                        // image, small row, small column of the thread's A rows (DOWN / UP)
+    bool pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pn[i] = pa[i] = pb[i] = 0; pv[i] = false; }
+    int py = 0, px = 0;
+    if (MODE == CONV_DOWN || MODE == CONV_UP) {
+        if (MODE == CONV_UP) { py = blockIdx.z >> 1; px = blockIdx.z & 1; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + srow + 32 * i;
+            pv[i] = m < pixels;
+            const int mm = pv[i] ? m : 0;
+            pn[i] = mm / (Hs * Ws);
+            const int r = mm - pn[i] * (Hs * Ws);
+            pa[i] = r / Ws;
+            pb[i] = r - pa[i] * Ws;
+        }
+    }
+    // WGRAD: the thread's 4 output columns (kh, kw, c) are fixed for the whole reduction
+    int w_kh = 0, w_kw = 0, w_c = 0;
+    bool w_nv = false;
+    if (MODE == CONV_WGRAD) {
+        const int col = n0 + 4 * b_rg;
+        w_nv = col < 16 * cb;
+        const int cell = (w_nv ? col : 0) / cb;
+        w_c = (w_nv ? col : 0) - cell * cb;
+        w_kh = cell >> 2; w_kw = cell & 3;
+    }
+
+    int nk, ks0 = 0;
+    if (MODE == CONV_DOWN) nk = 16 * cb / CV_BK;
+    else if (MODE == CONV_UP) nk = 4 * cs / CV_BK;
+    else {
+        const int nk_all = (pixels + CV_BK - 1) / CV_BK;
+        ks0 = blockIdx.z * G.ksteps_per_split;
+        nk = min(ks0 + G.ksteps_per_split, nk_all) - ks0;
+    }
+    const int nk_last = max(nk, 1) - 1;
+
+    // loads are unconditional: past the end they read the last step again (a branch around a step's loads would make
+    // every wait for loads a full one)
+#define CS_LOAD_A(v, ks_)                                                                                                \
+    {                                                                                                                    \
+        const int kst = min((ks_), nk_last);                                                                             \
+        if (MODE == CONV_DOWN) {                                                                                         \
+            const int k0 = kst * CV_BK, cell = k0 / cb, c0 = k0 - cell * cb + skq;                                       \
+            const int kh = cell >> 2, kw = cell & 3;                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+                const int y = 2 * pa[i] - 1 + kh, x = 2 * pb[i] - 1 + kw;                                                \
+                const bool ok = pv[i] && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;                       \
+                v[i] = ok ? *reinterpret_cast<const f32x4*>(G.T + ((int64_t)(pn[i] * Hb + y) * Wb + x) * cb + c0) : zero; \
+            }                                                                                                            \
+        } else if (MODE == CONV_UP) {                                                                                    \
+            const int k0 = kst * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs + skq;                                         \
+            const int th = tap >> 1, tw = tap & 1;                                                                       \
+            const int da = py ? (th ? 0 : 1) : (th ? -1 : 0), db = px ? (tw ? 0 : 1) : (tw ? -1 : 0);                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+                const int a = pa[i] + da, b = pb[i] + db;                                                                \
+                const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;                       \
+                v[i] = ok ? *reinterpret_cast<const f32x4*>(G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0) : zero; \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            /* S as (pixels, cs): 4 consecutive reduction rows m, the thread's 4 output rows j */                        \
+            const int j = m0 + 4 * a_rg;                                                                                 \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+                const int m = (ks0 + kst) * CV_BK + a_kq * 4 + q;                                                        \
+                v[q] = (a_on && m < pixels && j < cs) ? *reinterpret_cast<const f32x4*>(G.S + (int64_t)m * cs + j) : zero; \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+#define CS_LOAD_B(v, ks_)                                                                                                \
+    {                                                                                                                    \
+        const int kst = min((ks_), nk_last);                                                                             \
+        if (MODE == CONV_DOWN) {                                                                                         \
+            const int k = kst * CV_BK + skq;                                                                             \
+            _Pragma("unroll") for (int i = 0; i < NVB; ++i) {                                                            \
+                const int j = n0 + srow + 32 * i;                                                                        \
+                v[i] = j < cs ? *reinterpret_cast<const f32x4*>(G.Q + (int64_t)j * 16 * cb + k) : zero;                 \
+            }                                                                                                            \
+        } else if (MODE == CONV_UP) {                                                                                    \
+            const int k0 = kst * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs;                                               \
+            const int th = tap >> 1, tw = tap & 1;                                                                       \
+            const int kh = py ? (th ? 2 : 0) : (th ? 3 : 1), kw = px ? (tw ? 2 : 0) : (tw ? 3 : 1);                      \
+            const int c = n0 + 4 * b_rg;                                                                                 \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+                const int s = s0 + b_kq * 4 + q;                                                                         \
+                v[q] = (b_on && c < cb) ? *reinterpret_cast<const f32x4*>(G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c) : zero; \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            const int mb = (ks0 + kst) * CV_BK + b_kq * 4;                                                               \
+            const int mm = mb < pixels ? mb : 0;                                                                         \
+            int n = mm / (Hs * Ws);                                                                                      \
+            const int r = mm - n * (Hs * Ws);                                                                            \
+            int a = r / Ws, b = r - a * Ws;                                                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+                const int y = 2 * a - 1 + w_kh, x = 2 * b - 1 + w_kw;                                                    \
+                const bool ok = b_on && w_nv && mb + q < pixels && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb; \
+                v[q] = ok ? *reinterpret_cast<const f32x4*>(G.T + ((int64_t)(n * Hb + y) * Wb + x) * cb + w_c) : zero;  \
+                if (++b == Ws) { b = 0; if (++a == Hs) { a = 0; ++n; } }                                                 \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+    // registers -> LDS, split on the way
+#define CS_PUT_ROWK(S, KGS, PART, v, NV)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i)                                                                       \
+        cvs_put(S + (skq >> 3) * KGS + (srow + 32 * i) * 8 + (skq & 7), PART, v[i].x, v[i].y, v[i].z, v[i].w);
+#define CS_PUT_KROW(S, KGS, PART, R, rg, kq, on, v)                                                                      \
+    if (on) {                                                                                                            \
+        __bf16* const d_ = S + (kq >> 1) * KGS + rg * 8 + (kq & 1) * 4;                                                  \
+        cvs_put(d_, PART, v[0].x, v[1].x, v[2].x, v[3].x);                                                               \
+        cvs_put(d_ + (R / 4) * 8, PART, v[0].y, v[1].y, v[2].y, v[3].y);                                                 \
+        cvs_put(d_ + 2 * (R / 4) * 8, PART, v[0].z, v[1].z, v[2].z, v[3].z);                                             \
+        cvs_put(d_ + 3 * (R / 4) * 8, PART, v[0].w, v[1].w, v[2].w, v[3].w);                                             \
+    }
+#define CS_FRAG(S, KGS, PART, part, slot, half) \
+    (*reinterpret_cast<const cv_bf16x8*>(S + (part) * PART + (2 * (half) + lh) * KGS + (slot) * 8))
+
+    f32x4 a0[4], a1[4], b0[NVB], b1[NVB];
+    CS_LOAD_A(a0, 0) CS_LOAD_B(b0, 0)
+    CS_LOAD_A(a1, 1) CS_LOAD_B(b1, 1)
+
+    f32x16 acc[MT * NT];
+#pragma unroll
+    for (int i = 0; i < MT * NT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // one K-step from a register stage: LDS <- registers (split), then the requests for the step after next, then per
+    // 16 k the six partial products of every accumulator, smallest first, consecutive MFMAs on different accumulators
+#define CS_STEP(av, bv, ks_)                                                                                             \
+    {                                                                                                                    \
+        if ((ks_) > 0) __syncthreads();          /* every wave has read the previous step's images */                    \
+        if (A_ROWK) { CS_PUT_ROWK(sA, A_KGS, A_PART, av, 4) } else { CS_PUT_KROW(sA, A_KGS, A_PART, BM, a_rg, a_kq, a_on, av) } \
+        if (B_ROWK) { CS_PUT_ROWK(sB, B_KGS, B_PART, bv, NVB) } else { CS_PUT_KROW(sB, B_KGS, B_PART, BN, b_rg, b_kq, b_on, bv) } \
+        __syncthreads();                                                                                                 \
+        CS_LOAD_A(av, (ks_) + 2) CS_LOAD_B(bv, (ks_) + 2)                                                                \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                         \
+            cv_bf16x8 fa[MT][3], fb[NT][3];                                                                              \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) fa[i][p] = CS_FRAG(sA, A_KGS, A_PART, p, wm * 32 * MT + 32 * i + li, half); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                               \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) fb[j][p] = CS_FRAG(sB, B_KGS, B_PART, p, wn * 32 * NT + 32 * j + li, half); \
+            _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                              \
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};                                    \
+                _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
+                    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+                        acc[i * NT + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[t]], fb[j][PB[t]], acc[i * NT + j], 0, 0, 0); \
+            }                                                                                                            \
+        }                                                                                                                \
+    }
+
+    for (int ks = 0; ks < nk; ks += 2) {
+        CS_STEP(a0, b0, ks)
+        if (ks + 1 < nk) CS_STEP(a1, b1, ks + 1)
+    }
+#undef CS_LOAD_A
+#undef CS_LOAD_B
+#undef CS_PUT_ROWK
+#undef CS_PUT_KROW
+#undef CS_FRAG
+#undef CS_STEP
+
+    // ---- epilogue through LDS: MFMA rows back to tile rows, then every thread owns 4 consecutive columns of a row
+    __syncthreads();
+    float (*sC)[BN + 4] = reinterpret_cast<float (*)[BN + 4]>(smem_raw);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int cslot = wn * 32 * NT + 32 * j + li;
+            const int ccol = B_ROWK ? cslot : 4 * (cslot % (BN / 4)) + cslot / (BN / 4);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rslot = wm * 32 * MT + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int rrow = A_ROWK ? rslot : 4 * (rslot % (BM / 4)) + rslot / (BM / 4);
+                sC[rrow][ccol] = acc[i * NT + j][e];
+            }
+        }
+    __syncthreads();
+    constexpr int TPR = BN / 4;                 // threads per output row
+    const int c4 = (tid % TPR) * 4, col = n0 + c4;
+    const int ncols = MODE == CONV_DOWN ? cs : (MODE == CONV_UP ? cb : 16 * cb);
+    const int nrows = MODE == CONV_WGRAD ? cs : pixels;
+    if (col >= ncols) return;
+    for (int r = tid / TPR; r < BM; r += 256 / TPR) {
+        const int m = m0 + r;
+        if (m >= nrows) break;
+        const f32x4 y = *reinterpret_cast<const f32x4*>(&sC[r][c4]);
+        float* o;
+        if (MODE == CONV_DOWN) o = G.out + (int64_t)m * cs + col;
+        else if (MODE == CONV_UP) {
+            const int n = m / (Hs * Ws), rr = m - n * (Hs * Ws), a = rr / Ws, b = rr - a * Ws;
+            o = G.out + ((int64_t)(n * Hb + 2 * a + py) * Wb + 2 * b + px) * cb + col;
+        } else {
+            float* base = G.partial ? G.partial + (int64_t)blockIdx.z * cs * 16 * cb : G.out;
+            o = base + (int64_t)m * 16 * cb + col;
+        }
+        *reinterpret_cast<f32x4*>(o) = y;      // ncols % 4 == 0
+    }
+}
+
 // 128 x 128 output tiles (waves of 64 x 64) where the channel counts fill them: a third fewer operand bytes through the
 // vector caches per product than 128 x 64, and those bytes, not the matrix pipe, are what these kernels wait for
 static bool conv_wide_tiles(int channels) {
     return channels % 128 == 0 && std::getenv("DRM_CONV_NO_WIDE_TILES") == nullptr;
 }
 
+// the split form is the default; DRM_NO_SPLIT_PRODUCTS=1 (the switch of the large Linear products) keeps the fp32 MFMA form
+static bool conv_split_form() {
+    const char* e = std::getenv("DRM_NO_SPLIT_PRODUCTS");
+    return !(e && e[0] == '1');
+}
+
 static int wgrad_splits(int64_t pixels, int cs, int cb) {
     const int rows = conv_wide_tiles(cs) ? 128 : 64;
     const int64_t tiles = (int64_t)((cs + rows - 1) / rows) * ((16 * cb + 127) / 128);
     const int64_t nk = (pixels + CV_BK - 1) / CV_BK;
+    // two workgroups per CU; the split form has one LDS stage, so a workgroup alone on a CU cannot hide its staging
+    // behind another's MFMAs and the few-tile layers take up to 128 slices there (236 against 331 us for 64 x 512 outputs)
+    const int cap = conv_split_form() ? 128 : 64;
     int s = 1;
-    while (tiles * s < 512 && s * 2 <= 64 && nk / (s * 2) >= 8) s *= 2;
+    while (tiles * s < 512 && s * 2 <= cap && nk / (s * 2) >= 8) s *= 2;
     return s;
 }
 
@@ -332,10 +600,14 @@ extern "C" int drm_conv4s2_down(const float* big, const float* kernel, float* sm
     ConvArgs g{big, nullptr, kernel, small_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-    if (conv_wide_tiles(cs))
-        k_conv_gemm<CONV_DOWN, 2, 2><<<dim3(cs / 128, (unsigned)((pixels + 127) / 128), 1), dim3(256), 0, (hipStream_t)stream>>>(g);
+    const dim3 wide(cs / 128, (unsigned)((pixels + 127) / 128), 1), narrow((cs + 63) / 64, (unsigned)((pixels + 127) / 128), 1);
+    if (conv_split_form()) {
+        if (conv_wide_tiles(cs)) k_conv_split<CONV_DOWN, 2, 2><<<wide, dim3(256), 0, (hipStream_t)stream>>>(g);
+        else k_conv_split<CONV_DOWN, 2, 1><<<narrow, dim3(256), 0, (hipStream_t)stream>>>(g);
+    } else if (conv_wide_tiles(cs))
+        k_conv_gemm<CONV_DOWN, 2, 2><<<wide, dim3(256), 0, (hipStream_t)stream>>>(g);
     else
-        k_conv_gemm<CONV_DOWN, 2, 1><<<dim3((cs + 63) / 64, (unsigned)((pixels + 127) / 128), 1), dim3(256), 0, (hipStream_t)stream>>>(g);
+        k_conv_gemm<CONV_DOWN, 2, 1><<<narrow, dim3(256), 0, (hipStream_t)stream>>>(g);
     DRM_LAUNCH_CHECK();
     return DRM_OK;
 }
@@ -347,7 +619,13 @@ extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* bi
     ConvArgs g{nullptr, small, kernel, big_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-    if (cb <= 32 && std::getenv("DRM_CONV_NO_TALL_TILE") == nullptr)   // outputs of 32 columns: waves 4 x 1 over a 128 x 32 tile instead of half-empty 64-column tiles
+    const unsigned mtiles = (unsigned)((pixels + 127) / 128);
+    // outputs of 32 columns stay on the fp32 form: a 128 x 32 tile has too few MFMAs per staged value to pay for splitting it
+    // (266 against 252 us)
+    if (conv_split_form() && cb > 32) {
+        if (conv_wide_tiles(cb)) k_conv_split<CONV_UP, 2, 2><<<dim3(cb / 128, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+        else k_conv_split<CONV_UP, 2, 1><<<dim3((cb + 63) / 64, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    } else if (cb <= 32 && std::getenv("DRM_CONV_NO_TALL_TILE") == nullptr)   // outputs of 32 columns: waves 4 x 1 over a 128 x 32 tile instead of half-empty 64-column tiles
         // (a 256 x 32 tile moves fewer operand bytes per product but its 92 KB of LDS leave one workgroup per CU: 312 against 256 us)
         k_conv_gemm<CONV_UP, 1, 1, 1><<<dim3(1, (unsigned)((pixels + 127) / 128), 4), dim3(256), 0, (hipStream_t)stream>>>(g);
     else if (conv_wide_tiles(cb))
@@ -379,7 +657,10 @@ extern "C" int drm_conv4s2_wgrad(const float* small, const float* big, float* ke
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(PC_LINEAR_BIG, s, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-        if (conv_wide_tiles(cs)) k_conv_gemm<CONV_WGRAD, 2, 2><<<dim3((16 * cb + 127) / 128, cs / 128, splits), dim3(256), 0, s>>>(g);
+        if (conv_split_form()) {
+            if (conv_wide_tiles(cs)) k_conv_split<CONV_WGRAD, 2, 2><<<dim3((16 * cb + 127) / 128, cs / 128, splits), dim3(256), 0, s>>>(g);
+            else k_conv_split<CONV_WGRAD, 1, 2><<<dim3((16 * cb + 127) / 128, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
+        } else if (conv_wide_tiles(cs)) k_conv_gemm<CONV_WGRAD, 2, 2><<<dim3((16 * cb + 127) / 128, cs / 128, splits), dim3(256), 0, s>>>(g);
         else k_conv_gemm<CONV_WGRAD, 1, 2><<<dim3((16 * cb + 127) / 128, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
         DRM_LAUNCH_CHECK();
     }
