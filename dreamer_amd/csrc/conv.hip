@@ -305,29 +305,41 @@ __global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ p
 // a third of the pipe time of v_mfma_f32_32x32x2_f32 for the same reduction range.
 //
 // LDS image of an operand tile of R rows x 32 k, one per part: [k / 8][slot][8 k] (16 bytes per slot and k group; a
-// lane's MFMA fragment is one 16-byte read), k-group stride 16 R + 128 bytes so that the four k groups a staging wave
-// writes fall on the two halves of the banks.  Operands whose reduction index is contiguous in memory are staged as in
+// lane's MFMA fragment is one 16-byte read); the k groups start 0, 128, 64 and 192 bytes into the 256 bytes of the
+// banks, so that the four k groups that 32 lanes of a staging wave write (4 rows x 16 bytes each) fall on the four
+// quarters of the banks and the two k groups of one MFMA's fragments (lanes 0-31 / 32-63) on different halves.  Operands whose reduction index is contiguous in memory are staged as in
 // the fp32 form (slot = row).  The others (reduction index = pixel or input channel, rows contiguous) are loaded as
 // 4 k x 4 row blocks per thread -- rows 4 g ... 4 g + 3 of k quad q, 16 bytes per k -- and transposed in registers; row
-// 4 g + e goes to slot e R/4 + g, which makes the 8-byte LDS writes of a wave contiguous.  Which tile row an MFMA row
+// 4 g + e goes to slot e R/4 + g and neighbouring lanes hold the two k quads of a k group, which makes the 8-byte LDS
+// writes of 32 lanes one contiguous 256 bytes.  Which tile row an MFMA row
 // stands for is undone on the way out, in the epilogue's tile through LDS.
+__device__ __attribute__((aligned(16))) const float cv_zeros[4] = {0.f, 0.f, 0.f, 0.f};   // what a load of an invalid element reads
 typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cv_bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int cvs_kgs(int rows) { return rows * 8 + 64; }       // bf16 elements between k groups
+// element offset of k group kg (0 ... 3) in a part of R rows, and the elements of a part
+__device__ __host__ constexpr int cvs_kgo(int rows, int kg) { return kg * rows * 8 + 64 * (kg & 1) + 160 * (kg >> 1); }
+constexpr int cvs_part(int rows) { return 4 * rows * 8 + 256; }
 
+// four values -> their three bf16 parts, pairwise: one v_cvt_pk_bf16_f32 per pair and part, the parts widened back by a
+// shift / a mask, residuals as packed fp32 subtractions
+typedef float cv_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int cv_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvs_pack(cv_f32x2 v) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cv_bf16x2));
+}
+__device__ __forceinline__ cv_f32x2 cvs_widen(unsigned p) {
+    return cv_f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+}
 __device__ __forceinline__ void cvs_put(__bf16* dst, int part_stride, float f0, float f1, float f2, float f3) {
-    const float f[4] = {f0, f1, f2, f3};
-    cv_bf16x4 h, m, l;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        h[c] = (__bf16)f[c];
-        const float r1 = f[c] - (float)h[c];
-        m[c] = (__bf16)r1;
-        l[c] = (__bf16)(r1 - (float)m[c]);
-    }
-    *reinterpret_cast<cv_bf16x4*>(dst) = h;
-    *reinterpret_cast<cv_bf16x4*>(dst + part_stride) = m;
-    *reinterpret_cast<cv_bf16x4*>(dst + 2 * part_stride) = l;
+    const cv_f32x2 x0{f0, f1}, x1{f2, f3};
+    const unsigned h0 = cvs_pack(x0), h1 = cvs_pack(x1);
+    const cv_f32x2 r0 = x0 - cvs_widen(h0), r1 = x1 - cvs_widen(h1);
+    const unsigned m0 = cvs_pack(r0), m1 = cvs_pack(r1);
+    const cv_f32x2 q0 = r0 - cvs_widen(m0), q1 = r1 - cvs_widen(m1);
+    *reinterpret_cast<cv_u32x2*>(dst) = cv_u32x2{h0, h1};
+    *reinterpret_cast<cv_u32x2*>(dst + part_stride) = cv_u32x2{m0, m1};
+    *reinterpret_cast<cv_u32x2*>(dst + 2 * part_stride) = cv_u32x2{cvs_pack(q0), cvs_pack(q1)};
 }
 
 template <int MODE, int MT, int NT, int WN = 2>
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     constexpr int BM = 32 * MT * (4 / WN), BN = 32 * NT * WN;
     constexpr bool A_ROWK = MODE != CONV_WGRAD;     // DOWN / UP: A is [row][k]; WGRAD: A is [k][row]
     constexpr bool B_ROWK = MODE == CONV_DOWN;      // DOWN: B = Q rows [j][k]; UP / WGRAD: [k][col]
-    constexpr int A_KGS = cvs_kgs(BM), B_KGS = cvs_kgs(BN), A_PART = 4 * A_KGS, B_PART = 4 * B_KGS;
+    constexpr int A_KGS = BM, B_KGS = BN, A_PART = cvs_part(BM), B_PART = cvs_part(BN);      // (the macros' KGS = rows of the part)
     constexpr int STAGE_BYTES = 2 * 3 * (A_PART + B_PART), TILE_BYTES = 4 * BM * (BN + 4);
     constexpr int NVB = B_ROWK ? BN / 32 : 4;       // f32x4 per thread and K-step of the B tile (A: 4 either way)
     static_assert(A_ROWK ? BM == 128 : true, "pixel-row tiles are 128 rows");
@@ -346,14 +358,13 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     const int wm = WN == 2 ? (wave & 1) : wave, wn = WN == 2 ? (wave >> 1) : 0, li = lane & 31, lh = lane >> 5;
     const int Hs = G.Hs, Ws = G.Ws, cs = G.cs, cb = G.cb, Hb = 2 * Hs, Wb = 2 * Ws;
     const int pixels = G.NI * Hs * Ws;
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
     // [row][k] staging: rows (tid >> 3) + 32 i, k offset (tid & 7) * 4
     const int srow = tid >> 3, skq = (tid & 7) * 4;
     // [k][row] staging: row group and k quad of this thread's 4 x 4 block (threads past the tile's 8 k quads stage nothing)
-    const int a_rg = tid % (BM / 4), a_kq = tid / (BM / 4);
-    const int b_rg = tid % (BN / 4), b_kq = tid / (BN / 4);
+    const int a_rg = (tid >> 1) % (BM / 4), a_kq = (tid & 1) + 2 * ((tid >> 1) / (BM / 4));
+    const int b_rg = (tid >> 1) % (BN / 4), b_kq = (tid & 1) + 2 * ((tid >> 1) / (BN / 4));
     const bool a_on = A_ROWK || a_kq < 8, b_on = B_ROWK || b_kq < 8;
 
     int pn[4], pa[4], pb[4];                        // image, small row, small column of the thread's A rows (DOWN / UP)
@@ -385,6 +396,12 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
         w_kh = cell >> 2; w_kw = cell & 3;
     }
 
+    // order of the reduction: DOWN walks the 16 taps parity class by parity class ((kh, kw) = (0,0) (0,2) (2,0) (2,2),
+    // then (0,1) ...): the four taps of a class read the same input pixels shifted by one output pixel, so three of
+    // four staging loads of a tile hit lines the CU's vector cache just held, where the natural order comes back to a
+    // line 2 or 8 steps later, after the tile's other 16 or 128 KB.  UP walks the 4 taps (the 9 neighbours) inside a
+    // 32-channel chunk for the same reason.
+    const int cpc = cb / CV_BK;                     // K-steps per tap (DOWN)
     int nk, ks0 = 0;
     if (MODE == CONV_DOWN) nk = 16 * cb / CV_BK;
     else if (MODE == CONV_UP) nk = 4 * cs / CV_BK;
@@ -395,34 +412,36 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     }
     const int nk_last = max(nk, 1) - 1;
 
-    // loads are unconditional: past the end they read the last step again (a branch around a step's loads would make
-    // every wait for loads a full one)
+    // loads are unconditional -- an invalid element reads 16 bytes of zeros instead, steps past the end read the last
+    // step again: a branch around a load makes the compiler wait for every outstanding load at the join, i.e. for the
+    // loads just issued
 #define CS_LOAD_A(v, ks_)                                                                                                \
     {                                                                                                                    \
         const int kst = min((ks_), nk_last);                                                                             \
         if (MODE == CONV_DOWN) {                                                                                         \
-            const int k0 = kst * CV_BK, cell = k0 / cb, c0 = k0 - cell * cb + skq;                                       \
-            const int kh = cell >> 2, kw = cell & 3;                                                                     \
+            const int t = kst / cpc, kh = ((t >> 3) & 1) + ((t >> 1) & 1) * 2, kw = ((t >> 2) & 1) + (t & 1) * 2;         \
+            const int c0 = (kst - t * cpc) * CV_BK + skq;                                                                \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
                 const int y = 2 * pa[i] - 1 + kh, x = 2 * pb[i] - 1 + kw;                                                \
                 const bool ok = pv[i] && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb;                       \
-                v[i] = ok ? *reinterpret_cast<const f32x4*>(G.T + ((int64_t)(pn[i] * Hb + y) * Wb + x) * cb + c0) : zero; \
+                v[i] = *reinterpret_cast<const f32x4*>(ok ? G.T + ((int64_t)(pn[i] * Hb + y) * Wb + x) * cb + c0 : cv_zeros); \
             }                                                                                                            \
         } else if (MODE == CONV_UP) {                                                                                    \
-            const int k0 = kst * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs + skq;                                         \
+            const int tap = kst & 3, s0 = (kst >> 2) * CV_BK + skq;                                                      \
             const int th = tap >> 1, tw = tap & 1;                                                                       \
             const int da = py ? (th ? 0 : 1) : (th ? -1 : 0), db = px ? (tw ? 0 : 1) : (tw ? -1 : 0);                    \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
                 const int a = pa[i] + da, b = pb[i] + db;                                                                \
                 const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;                       \
-                v[i] = ok ? *reinterpret_cast<const f32x4*>(G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0) : zero; \
+                v[i] = *reinterpret_cast<const f32x4*>(ok ? G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0 : cv_zeros); \
             }                                                                                                            \
         } else {                                                                                                         \
             /* S as (pixels, cs): 4 consecutive reduction rows m, the thread's 4 output rows j */                        \
             const int j = m0 + 4 * a_rg;                                                                                 \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
                 const int m = (ks0 + kst) * CV_BK + a_kq * 4 + q;                                                        \
-                v[q] = (a_on && m < pixels && j < cs) ? *reinterpret_cast<const f32x4*>(G.S + (int64_t)m * cs + j) : zero; \
+                const bool ok = a_on && m < pixels && j < cs;                                                            \
+                v[q] = *reinterpret_cast<const f32x4*>(ok ? G.S + (int64_t)m * cs + j : cv_zeros);                           \
             }                                                                                                            \
         }                                                                                                                \
     }
@@ -430,19 +449,21 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     {                                                                                                                    \
         const int kst = min((ks_), nk_last);                                                                             \
         if (MODE == CONV_DOWN) {                                                                                         \
-            const int k = kst * CV_BK + skq;                                                                             \
+            const int t = kst / cpc, kh = ((t >> 3) & 1) + ((t >> 1) & 1) * 2, kw = ((t >> 2) & 1) + (t & 1) * 2;         \
+            const int k = (kh * 4 + kw) * cb + (kst - t * cpc) * CV_BK + skq;                                            \
             _Pragma("unroll") for (int i = 0; i < NVB; ++i) {                                                            \
                 const int j = n0 + srow + 32 * i;                                                                        \
-                v[i] = j < cs ? *reinterpret_cast<const f32x4*>(G.Q + (int64_t)j * 16 * cb + k) : zero;                 \
+                v[i] = *reinterpret_cast<const f32x4*>(j < cs ? G.Q + (int64_t)j * 16 * cb + k : cv_zeros);                  \
             }                                                                                                            \
         } else if (MODE == CONV_UP) {                                                                                    \
-            const int k0 = kst * CV_BK, tap = k0 / cs, s0 = k0 - tap * cs;                                               \
+            const int tap = kst & 3, s0 = (kst >> 2) * CV_BK;                                                            \
             const int th = tap >> 1, tw = tap & 1;                                                                       \
             const int kh = py ? (th ? 2 : 0) : (th ? 3 : 1), kw = px ? (tw ? 2 : 0) : (tw ? 3 : 1);                      \
             const int c = n0 + 4 * b_rg;                                                                                 \
+            const bool ok = b_on && c < cb;                                                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
                 const int s = s0 + b_kq * 4 + q;                                                                         \
-                v[q] = (b_on && c < cb) ? *reinterpret_cast<const f32x4*>(G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c) : zero; \
+                v[q] = *reinterpret_cast<const f32x4*>(ok ? G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c : cv_zeros);      \
             }                                                                                                            \
         } else {                                                                                                         \
             const int mb = (ks0 + kst) * CV_BK + b_kq * 4;                                                               \
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
                 const int y = 2 * a - 1 + w_kh, x = 2 * b - 1 + w_kw;                                                    \
                 const bool ok = b_on && w_nv && mb + q < pixels && (unsigned)y < (unsigned)Hb && (unsigned)x < (unsigned)Wb; \
-                v[q] = ok ? *reinterpret_cast<const f32x4*>(G.T + ((int64_t)(n * Hb + y) * Wb + x) * cb + w_c) : zero;  \
+                v[q] = *reinterpret_cast<const f32x4*>(ok ? G.T + ((int64_t)(n * Hb + y) * Wb + x) * cb + w_c : cv_zeros);   \
                 if (++b == Ws) { b = 0; if (++a == Hs) { a = 0; ++n; } }                                                 \
             }                                                                                                            \
         }                                                                                                                \
@@ -461,17 +482,17 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     // registers -> LDS, split on the way
 #define CS_PUT_ROWK(S, KGS, PART, v, NV)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < NV; ++i)                                                                       \
-        cvs_put(S + (skq >> 3) * KGS + (srow + 32 * i) * 8 + (skq & 7), PART, v[i].x, v[i].y, v[i].z, v[i].w);
+        cvs_put(S + cvs_kgo(KGS, skq >> 3) + (srow + 32 * i) * 8 + (skq & 7), PART, v[i].x, v[i].y, v[i].z, v[i].w);
 #define CS_PUT_KROW(S, KGS, PART, R, rg, kq, on, v)                                                                      \
     if (on) {                                                                                                            \
-        __bf16* const d_ = S + (kq >> 1) * KGS + rg * 8 + (kq & 1) * 4;                                                  \
+        __bf16* const d_ = S + cvs_kgo(KGS, kq >> 1) + rg * 8 + (kq & 1) * 4;                                            \
         cvs_put(d_, PART, v[0].x, v[1].x, v[2].x, v[3].x);                                                               \
         cvs_put(d_ + (R / 4) * 8, PART, v[0].y, v[1].y, v[2].y, v[3].y);                                                 \
         cvs_put(d_ + 2 * (R / 4) * 8, PART, v[0].z, v[1].z, v[2].z, v[3].z);                                             \
         cvs_put(d_ + 3 * (R / 4) * 8, PART, v[0].w, v[1].w, v[2].w, v[3].w);                                             \
     }
 #define CS_FRAG(S, KGS, PART, part, slot, half) \
-    (*reinterpret_cast<const cv_bf16x8*>(S + (part) * PART + (2 * (half) + lh) * KGS + (slot) * 8))
+    (*reinterpret_cast<const cv_bf16x8*>(S + (part) * PART + cvs_kgo(KGS, 2 * (half) + lh) + (slot) * 8))
 
     f32x4 a0[4], a1[4], b0[NVB], b1[NVB];
     CS_LOAD_A(a0, 0) CS_LOAD_B(b0, 0)
@@ -485,13 +506,13 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
 
     // one K-step from a register stage: LDS <- registers (split), then the requests for the step after next, then per
     // 16 k the six partial products of every accumulator, smallest first, consecutive MFMAs on different accumulators
-#define CS_STEP(av, bv, ks_)                                                                                             \
+#define CS_STEP(av, bv, ks_)                                                                                                       \
     {                                                                                                                    \
         if ((ks_) > 0) __syncthreads();          /* every wave has read the previous step's images */                    \
         if (A_ROWK) { CS_PUT_ROWK(sA, A_KGS, A_PART, av, 4) } else { CS_PUT_KROW(sA, A_KGS, A_PART, BM, a_rg, a_kq, a_on, av) } \
         if (B_ROWK) { CS_PUT_ROWK(sB, B_KGS, B_PART, bv, NVB) } else { CS_PUT_KROW(sB, B_KGS, B_PART, BN, b_rg, b_kq, b_on, bv) } \
         __syncthreads();                                                                                                 \
-        CS_LOAD_A(av, (ks_) + 2) CS_LOAD_B(bv, (ks_) + 2)                                                                \
+        CS_LOAD_A(av, (ks_) + 2) CS_LOAD_B(bv, (ks_) + 2)                                                                          \
         _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                         \
             cv_bf16x8 fa[MT][3], fb[NT][3];                                                                              \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
@@ -554,6 +575,144 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
             o = base + (int64_t)m * 16 * cb + col;
         }
         *reinterpret_cast<f32x4*>(o) = y;      // ncols % 4 == 0
+    }
+}
+
+// UP for outputs of at most 32 channels, split form: the four parity classes of a 128-pixel tile in one workgroup.
+// A class-by-class launch reads every small-resolution pixel 16 times (4 classes x 4 taps) for 32 output columns each,
+// too few MFMAs per staged value; here the reduction runs over the 9 neighbours (da, db) of the small pixel, each
+// staged (and split) once and multiplied into the 1, 2 or 4 classes that meet it: class (py, px) meets neighbour
+// da in {0, py ? +1 : -1} through kh = 1 + py - 2 da (columns alike).  Wave w owns rows 32 w ... of the tile and one
+// 32 x 32 accumulator per class, and stages the weights of class w (32 k x 32 c per step, transposed into
+// [k / 8][slot][8 k] like every [k][col] operand of k_conv_split).  Outputs go from the accumulators straight to
+// memory: the 32 lanes of an accumulator row hold the 32 channels of one output pixel, one 128-byte line.
+__global__ __launch_bounds__(256) void k_conv_up4_split(const ConvArgs G) {
+    constexpr int A_KGS = 128, A_PART = cvs_part(128);
+    constexpr int B_KGS = 32, B_PART = cvs_part(32), B_CLASS = 3 * B_PART;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[3 * A_PART + 4 * B_CLASS];
+    __shared__ int s_pix[128];
+    __bf16* const sA = smem;
+    __bf16* const sB = smem + 3 * A_PART;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int Hs = G.Hs, Ws = G.Ws, cs = G.cs, cb = G.cb, Hb = 2 * Hs, Wb = 2 * Ws;
+    const int pixels = G.NI * Hs * Ws;
+    const int m0 = blockIdx.x * 128;
+    const int srow = tid >> 3, skq = (tid & 7) * 4;
+    const int b_rg = lane & 7, b_kq = lane >> 3;        // this thread's 4 x 4 block of its wave's class: channels 4 b_rg ..., k quad b_kq
+    const int upy = wave >> 1, upx = wave & 1;
+    const int cpk = cs / CV_BK, nk = 9 * cpk;
+
+    int pn[4], pa[4], pb[4];
+    bool pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + srow + 32 * i;
+        pv[i] = m < pixels;
+        const int mm = pv[i] ? m : 0;
+        pn[i] = mm / (Hs * Ws);
+        const int r = mm - pn[i] * (Hs * Ws);
+        pa[i] = r / Ws;
+        pb[i] = r - pa[i] * Ws;
+    }
+
+#define U4_NEIGHBOUR(kst)                                                                                                \
+    const int nb = (kst) % 9, s0 = ((kst) / 9) * CV_BK;                                                                  \
+    const int da = nb / 3 - 1, db = nb - (nb / 3) * 3 - 1;
+#define U4_MEETS(py_, px_) ((da == 0 || da == ((py_) ? 1 : -1)) && (db == 0 || db == ((px_) ? 1 : -1)))
+    /* unconditional loads, as in k_conv_split */                                                                        \
+#define U4_LOAD(av, bv, ks_)                                                                                             \
+    {                                                                                                                    \
+        U4_NEIGHBOUR(min((ks_), nk - 1))                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+            const int a = pa[i] + da, b = pb[i] + db;                                                                    \
+            const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;                           \
+            av[i] = *reinterpret_cast<const f32x4*>(ok ? G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0 + skq : cv_zeros); \
+        }                                                                                                                \
+        const bool use = U4_MEETS(upy, upx) && 4 * b_rg < cb;                                                            \
+        const int kh = 1 + upy - 2 * da, kw = 1 + upx - 2 * db;                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                    \
+            bv[q] = *reinterpret_cast<const f32x4*>(use ? G.Q + ((int64_t)(s0 + 4 * b_kq + q) * 16 + kh * 4 + kw) * cb + 4 * b_rg : cv_zeros); \
+    }
+#define U4_FRAG(S, KGS, PART, part, slot, half) \
+    (*reinterpret_cast<const cv_bf16x8*>(S + (part) * PART + cvs_kgo(KGS, 2 * (half) + lh) + (slot) * 8))
+#define U4_CLASS(v, half)                                                                                                \
+    if (U4_MEETS((v) >> 1, (v) & 1)) {                                                                                   \
+        const cv_bf16x8 bh = U4_FRAG(sB + (v) * B_CLASS, B_KGS, B_PART, 0, li, half),                                    \
+                        bm = U4_FRAG(sB + (v) * B_CLASS, B_KGS, B_PART, 1, li, half),                                    \
+                        bl = U4_FRAG(sB + (v) * B_CLASS, B_KGS, B_PART, 2, li, half);                                    \
+        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[v], 0, 0, 0);                                       \
+        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[v], 0, 0, 0);                                       \
+        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[v], 0, 0, 0);                                       \
+        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[v], 0, 0, 0);                                       \
+        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[v], 0, 0, 0);                                       \
+        acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[v], 0, 0, 0);                                       \
+    }
+#define U4_STEP(av, bv, ks_)                                                                                                 \
+    {                                                                                                                    \
+        U4_NEIGHBOUR(ks_)                                                                                                \
+        (void)s0;                                                                                                        \
+        if ((ks_) > 0) __syncthreads();                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+            cvs_put(sA + cvs_kgo(A_KGS, skq >> 3) + (srow + 32 * i) * 8 + (skq & 7), A_PART, av[i].x, av[i].y, av[i].z, av[i].w); \
+                                                                                                                         \
+        if (U4_MEETS(upy, upx)) {                                                                                        \
+            __bf16* const d_ = sB + wave * B_CLASS + cvs_kgo(B_KGS, b_kq >> 1) + b_rg * 8 + (b_kq & 1) * 4;               \
+            cvs_put(d_, B_PART, bv[0].x, bv[1].x, bv[2].x, bv[3].x);                                                     \
+            cvs_put(d_ + 64, B_PART, bv[0].y, bv[1].y, bv[2].y, bv[3].y);                                                \
+            cvs_put(d_ + 128, B_PART, bv[0].z, bv[1].z, bv[2].z, bv[3].z);                                               \
+            cvs_put(d_ + 192, B_PART, bv[0].w, bv[1].w, bv[2].w, bv[3].w);                                               \
+        }                                                                                                                \
+        __syncthreads();                                                                                                 \
+        U4_LOAD(av, bv, (ks_) + 2)                                                                                           \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                         \
+            const cv_bf16x8 ah = U4_FRAG(sA, A_KGS, A_PART, 0, wave * 32 + li, half),                                    \
+                            am = U4_FRAG(sA, A_KGS, A_PART, 1, wave * 32 + li, half),                                    \
+                            al = U4_FRAG(sA, A_KGS, A_PART, 2, wave * 32 + li, half);                                    \
+            U4_CLASS(0, half) U4_CLASS(1, half) U4_CLASS(2, half) U4_CLASS(3, half)                                      \
+        }                                                                                                                \
+    }
+
+    f32x4 a0[4], a1[4], b0[4], b1[4];
+    U4_LOAD(a0, b0, 0)
+    U4_LOAD(a1, b1, 1)
+    f32x16 acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
+
+    for (int ks = 0; ks < nk; ks += 2) {       // nk = 9 cs / 32 >= 9; an odd count ends on the first stage
+        U4_STEP(a0, b0, ks)
+        if (ks + 1 < nk) U4_STEP(a1, b1, ks + 1)
+    }
+#undef U4_NEIGHBOUR
+#undef U4_MEETS
+#undef U4_LOAD
+#undef U4_FRAG
+#undef U4_CLASS
+#undef U4_STEP
+
+    // ---- outputs: big-resolution pixel (2a + py, 2b + px) of every tile row, channel 4 (li % 8) + li / 8 in lane li
+    if (tid < 128) {
+        const int m = m0 + tid;
+        int p = -1;
+        if (m < pixels) {
+            const int n = m / (Hs * Ws), r = m - n * (Hs * Ws), a = r / Ws, b = r - a * Ws;
+            p = (n * Hb + 2 * a) * Wb + 2 * b;
+        }
+        s_pix[tid] = p;
+    }
+    __syncthreads();
+    const int col = 4 * (li & 7) + (li >> 3);
+    if (col >= cb) return;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int shift = (v >> 1) * Wb + (v & 1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int p = s_pix[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh];
+            if (p >= 0) G.out[(int64_t)(p + shift) * cb + col] = acc[v][e];
+        }
     }
 }
 
@@ -620,9 +779,11 @@ extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* bi
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
     const unsigned mtiles = (unsigned)((pixels + 127) / 128);
-    // outputs of 32 columns stay on the fp32 form: a 128 x 32 tile has too few MFMAs per staged value to pay for splitting it
-    // (266 against 252 us)
-    if (conv_split_form() && cb > 32) {
+    // outputs of 32 columns: all four parity classes per workgroup (class by class a 128 x 32 tile has too few MFMAs per
+    // staged value to pay for splitting it: 266 against 252 us of the fp32 form)
+    if (conv_split_form() && cb <= 32 && std::getenv("DRM_CONV_NO_UP4") == nullptr)
+        k_conv_up4_split<<<dim3(mtiles), dim3(256), 0, (hipStream_t)stream>>>(g);
+    else if (conv_split_form() && cb > 32) {
         if (conv_wide_tiles(cb)) k_conv_split<CONV_UP, 2, 2><<<dim3(cb / 128, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
         else k_conv_split<CONV_UP, 2, 1><<<dim3((cb + 63) / 64, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
     } else if (cb <= 32 && std::getenv("DRM_CONV_NO_TALL_TILE") == nullptr)   // outputs of 32 columns: waves 4 x 1 over a 128 x 32 tile instead of half-empty 64-column tiles

@@ -14,8 +14,9 @@ def _close(got, ref, tol=3e-6):
     assert float((got.double() - ref).abs().max()) <= tol * scale, (float((got.double() - ref).abs().max()), scale)
 
 
-# (images, small H, small W, cs, cb): the six middle layers of the default towers at a reduced batch, odd sizes, one pixel
-LAYERS = [(20, 16, 16, 64, 32), (20, 8, 8, 128, 64), (20, 4, 4, 256, 128), (3, 5, 7, 32, 32), (2, 1, 1, 64, 96), (70, 2, 3, 36, 64)]
+# (images, small H, small W, cs, cb): the six middle layers of the default towers at a reduced batch, odd sizes, one pixel,
+# fewer than 32 big-resolution channels
+LAYERS = [(20, 16, 16, 64, 32), (20, 8, 8, 128, 64), (20, 4, 4, 256, 128), (3, 5, 7, 32, 32), (2, 1, 1, 64, 96), (70, 2, 3, 36, 64), (5, 3, 5, 32, 12)]
 
 
 @pytest.mark.parametrize("ni,hs,ws,cs,cb", LAYERS)

@@ -31,7 +31,8 @@ for cs, cb, hs in ((64, 32, 16), (128, 64, 8), (256, 128, 4)):
     t_down = timed(lambda: N.conv4s2_down(big, kern))
     t_up = timed(lambda: N.conv4s2_up(small, kern))
     t_wg = timed(lambda: N.conv4s2_wgrad(small, big))
-    b_down = timed(lambda: F.conv2d(big, kern, None, 2, 1))
-    b_up = timed(lambda: F.conv_transpose2d(small, kern, None, 2, 1))
+    no_backend = os.environ.get("CONV_TIMES_NO_BACKEND") == "1"      # counter passes: the library's kernels only
+    b_down = 0.0 if no_backend else timed(lambda: F.conv2d(big, kern, None, 2, 1))
+    b_up = 0.0 if no_backend else timed(lambda: F.conv_transpose2d(small, kern, None, 2, 1))
     print(f"cs={cs:3d} cb={cb:3d} hs={hs:2d} ({gf:.1f} GFLOP): down {t_down:6.1f} us {gf / t_down * 1e3:6.1f} TF (backend {b_down:6.1f}) | "
           f"up {t_up:6.1f} us {gf / t_up * 1e3:6.1f} TF (backend {b_up:6.1f}) | wgrad {t_wg:6.1f} us {gf / t_wg * 1e3:6.1f} TF", flush=True)
