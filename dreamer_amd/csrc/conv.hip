@@ -1,6 +1,8 @@
 // Stride-2 4x4 convolutions of the encoder / decoder towers (nn.Conv2d(k4, s2, p1), lib/world_model.py:94-108, and
-// nn.ConvTranspose2d(k4, s2, p1), lib/world_model.py:290-302) as implicit matrix products on the fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32), activations in channels-last memory (N, H, W, C), no im2col buffer.
+// nn.ConvTranspose2d(k4, s2, p1), lib/world_model.py:290-302) as implicit matrix products on the matrix cores,
+// activations in channels-last memory (N, H, W, C), no im2col buffer.  Two forms with the same results to fp32 rounding:
+// k_conv_gemm on v_mfma_f32_32x32x2_f32, and (the default) k_conv_split / k_conv_up4_split on v_mfma_f32_32x32x16_bf16
+// with both operands split exactly into three bf16 parts.
 //
 // One layer relates a big-resolution tensor T (NI, 2Hs, 2Ws, cb) and a small-resolution tensor S (NI, Hs, Ws, cs)
 // through a kernel Q stored [cs][kh][kw][cb]: nn.Conv2d maps T -> S (Q = weight (cs, cb, 4, 4) in channels-last
@@ -13,7 +15,7 @@
 //                          (per parity class of p only 2 x 2 of the 16 taps meet a small pixel)
 //   WGRAD dQ[j, kh,kw,c] = sum_m         S[m, j] T[pix(m; kh,kw), c]                weight gradient of both
 //
-// Workgroup = 4 waves = 64 x 64 output tile (2 x 2 waves, one 32 x 32 accumulator each), reduction in steps of 32
+// k_conv_gemm: workgroup = 4 waves = 64 x 64 output tile (2 x 2 waves, one 32 x 32 accumulator each), reduction in steps of 32
 // through two LDS buffers with two register stages of global loads in flight.  Operands whose reduction index is
 // contiguous in memory are staged [row][k] (stride 36 words, 16-byte fragment reads), the others [k][row] (stride 68,
 // one word per lane and MFMA).  WGRAD splits its long reduction (all output pixels) over blockIdx.z into partial
