@@ -143,6 +143,7 @@ SIGNATURES = {
     "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_split": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "drm_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_gemm_f32": (C.c_int, [C.c_int32] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "drm_pack_imagine_bytes": (C.c_size_t, [C.POINTER(drm_dims)]),
@@ -305,7 +306,7 @@ def ln_silu_backward(x, dy, gamma, beta, mean, rstd, channel_bias=None, want_dx_
     check(lib().drm_ln_silu_backward(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                      rstd.data_ptr(), dx.data_ptr(), part.data_ptr(), N, E, ptr(channel_bias), hw, int(cl),
                                      ptr(sums), stream_ptr(x.device)), "drm_ln_silu_backward")
-    total = part.sum(0)
+    total = sum_rows(part.view(slices, rows * E)).view(rows, E)
     if rows == 2:
         return dx, total
     if channel_bias is None:
@@ -554,6 +555,26 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
                              c.data_ptr(), c.stride(0), ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(a.device)),
           "drm_gemm_f32")
     return c
+
+
+def colsum_ok(x: torch.Tensor) -> bool:
+    """Whether ``colsum`` takes x: a 2-D fp32 device matrix with contiguous 16-byte aligned rows, columns a multiple of 4."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 1 and x.shape[1] >= 4 and x.shape[1] % 4 == 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) >= x.shape[1] and x.data_ptr() % 16 == 0)
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """x.sum(0) of a (rows, cols) matrix on the library's kernel (rows added in a fixed order)."""
+    if not colsum_ok(x):
+        raise NativeError("colsum: operand must be an fp32 device matrix with contiguous, 16-byte aligned rows and cols % 4 == 0")
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    check(lib().drm_colsum_f32(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), stream_ptr(x.device)), "drm_colsum_f32")
+    return out
+
+
+def sum_rows(x: torch.Tensor) -> torch.Tensor:
+    """x.sum(0) for a 2-D tensor: the library's kernel where it applies, torch's otherwise."""
+    return colsum(x) if colsum_ok(x) else x.sum(0)
 
 
 def _cl4(x: torch.Tensor, name: str) -> torch.Tensor:

@@ -202,6 +202,39 @@ static int gemm_splits(int M, int N, int K) {
     return s;
 }
 
+// Column sums of a row-major matrix: out[c] = sum_r X[r, c] (bias gradients of the batched Linear layers, slice sums of
+// the LayerNorm parameter gradients).  A workgroup owns 16 columns: 4 threads x 16 bytes across, 64 row groups down; a
+// thread adds every 64th row, then the row groups are added through LDS in a fixed order (same bits every time).
+// Narrow strips on purpose: a 1024 x 512 matrix becomes 32 workgroups of 16 loads per thread instead of 2 of 256.
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, int64_t ldx, int rows, int cols, float* __restrict__ out) {
+    __shared__ f32x4 part[64][4];
+    const int tid = threadIdx.x, cq = tid & 3, rg = tid >> 2;
+    const int c = blockIdx.x * 16 + cq * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < cols) {                               // cols % 4 == 0
+        const float* p = X + (int64_t)rg * ldx + c;
+        int r = rg;
+#pragma unroll 1
+        for (; r + 7 * 64 < rows; r += 8 * 64) {   // eight independent loads in flight
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)u * 64 * ldx);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+            p += (int64_t)8 * 64 * ldx;
+        }
+        for (; r < rows; r += 64) { acc += *reinterpret_cast<const f32x4*>(p); p += (int64_t)64 * ldx; }
+    }
+    part[rg][cq] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (rg < h) part[rg][cq] += part[rg + h][cq];
+        __syncthreads();
+    }
+    if (rg == 0 && c < cols) *reinterpret_cast<f32x4*>(out + c) = part[0][cq];
+}
+
 }  // namespace drm
 
 using namespace drm;
@@ -247,5 +280,16 @@ extern "C" int drm_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t
         k_gemm_reduce<<<dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s>>>(g.partial, splits, M, N, bias, C, ldc);
         DRM_LAUNCH_CHECK();
     }
+    return DRM_OK;
+}
+
+extern "C" int drm_colsum_f32(const float* x, int64_t ldx, int32_t rows, int32_t cols, float* out, drm_stream_t stream) {
+    DRM_REQUIRE(x && out, DRM_EINVAL, "null pointer");
+    DRM_REQUIRE(rows >= 1 && cols >= 4 && cols % 4 == 0 && ldx >= cols && ldx % 4 == 0, DRM_EINVAL, "rows=%d cols=%d ldx=%lld (multiples of 4)",
+                rows, cols, (long long)ldx);
+    DRM_REQUIRE(aligned16(x) && aligned16(out), DRM_EINVAL, "tensors must be 16-byte aligned");
+    ProfScope prof(PC_ELEMENTWISE, (hipStream_t)stream, (double)rows * cols, 4.0 * ((double)rows * cols + cols));
+    k_colsum<<<dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, rows, cols, out);
+    DRM_LAUNCH_CHECK();
     return DRM_OK;
 }

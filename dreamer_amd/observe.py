@@ -180,7 +180,7 @@ class ObserveScanFn(torch.autograd.Function):
         g_lin_w = torch.cat([_mm_wgrad(dx2, z_in), _mm_wgrad(dx2, a_vec)], dim=1)
         g_a_emb = torch.zeros_like(a_emb).index_add_(0, a2, _mm_dgrad(dx2, lin_w[:, LK:]) * c2)
         g_fc = _mm_wgrad(d_post.reshape(B * T, LK), h.reshape(B * T, D))
-        return (None, d_post.reshape(B, T, LK), g_a_emb, g_lin_w, dx2.sum(0), g_w_ih, g_w_hh, gi2.sum(0), gh2.sum(0), g_fc,
+        return (None, d_post.reshape(B, T, LK), g_a_emb, g_lin_w, N.sum_rows(dx2), g_w_ih, g_w_hh, N.sum_rows(gi2), N.sum_rows(gh2), g_fc,
                 None, None, None, None, None, None)
 
 

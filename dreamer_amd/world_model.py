@@ -127,7 +127,10 @@ class _LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = _mm_dgrad(dy, w, ctx.form) if ctx.needs_input_grad[0] else None
         dw = _mm_wgrad(dy, x, ctx.form) if ctx.needs_input_grad[1] else None
-        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            from . import _native as N
+            db = N.sum_rows(dy)
         return dx, dw, db
 
 

@@ -251,6 +251,11 @@ int drm_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t
                  const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, void* workspace,
                  size_t workspace_bytes, drm_stream_t stream);
 
+/* Column sums of a row-major fp32 matrix, out[c] = sum_r x[r, c], rows added in a fixed order: the bias gradient autograd
+ * forms for nn.Linear (lib/world_model.py:153-160 etc.: grad_bias = grad_output.sum(0)) and the sum over the slices of
+ * the LayerNorm parameter-gradient partials (drm_ln_silu_backward).  cols and ldx multiples of 4, 16-byte aligned. */
+int drm_colsum_f32(const float* x, int64_t ldx, int32_t rows, int32_t cols, float* out, drm_stream_t stream);
+
 /* ---- imagination block: lib/trainer.py:176-224 ----------------------------------------------
  * actor -> sample action -> WorldModel.step(prior) for H steps, then reward / continue heads,
  * critic value and the lambda-return, for B independent trajectories.  The decoder call of

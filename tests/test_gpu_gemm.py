@@ -49,3 +49,20 @@ def test_linear_autograd_function_matches_torch():
     rx, rw, rb = torch.autograd.grad(ref, (x, lin.weight, lin.bias), gy.double())
     for got, want in ((gx, rx), (gw, rw), (gb, rb)):
         assert float((got.double() - want.double()).abs().max()) <= 3e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("rows,cols,ld", [(1024, 512, 512), (128, 1536, 1536), (32, 98304, 98304), (7, 4, 4), (1000, 20, 36), (513, 4096, 4096), (1, 8, 8)])
+def test_column_sums_against_fp64(rows, cols, ld):
+    """Bias gradients / slice sums: out[c] = sum_r x[r, c], also for a matrix whose rows are longer than its columns."""
+    g = torch.Generator().manual_seed(rows + cols)
+    full = torch.randn(rows, ld, generator=g).to(DEV)
+    x = full[:, :cols]
+    assert N.colsum_ok(x)
+    got = N.colsum(x)
+    ref = x.double().sum(0)
+    assert got.shape == (cols,)
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * float(x.abs().sum(0).max())
+    assert torch.equal(got, N.colsum(x))            # fixed order of the rows: the same bits every time
+    assert torch.equal(N.sum_rows(x), got)
+    odd = torch.randn(5, 7, device=DEV)             # shapes the kernel does not take fall back to torch
+    assert not N.colsum_ok(odd) and torch.equal(N.sum_rows(odd), odd.sum(0))

@@ -22,4 +22,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for _ in range(3):
         L.update(buf.sample(16, want_f32=True))
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("ROWS", "40")), max_name_column_width=50, max_shapes_column_width=70))
+if os.environ.get("COMPACT") == "1":     # one line per (op, input shapes): device time per update, launches per update, average
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    for e in rows[:int(os.environ.get("ROWS", "40"))]:
+        print(f"{e.self_device_time_total / 3:8.1f} us/update {e.count / 3:6.1f} x {e.self_device_time_total / e.count:7.1f} us  {e.key[:44]:44s} {str(e.input_shapes)[:110]}")
+else:
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=int(os.environ.get("ROWS", "40")), max_name_column_width=50, max_shapes_column_width=70))
