@@ -15,6 +15,7 @@
 // a half-wave read 32 consecutive words).  Problems with few output tiles split K over blockIdx.z into partial tiles
 // in a workspace, summed in a fixed order by a second kernel (no atomics: results do not depend on timing).
 #include "common.hpp"
+#include <cstdlib>
 #include "../../include/dreamer_amd.h"
 
 namespace drm {
@@ -197,8 +198,11 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(const float* __restrict__ p
 static int gemm_splits(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
     const int nk = (K + GM_BK - 1) / GM_BK;
+    // one workgroup per CU, two for long reductions (K >= 2048: 1024 x 1536 x 4096 181 -> 128 us, 1024 x 1024 x 4096 104 -> 90 us;
+    // short ones lose more to the summing kernel than they gain); at least 4 K-steps per slice
+    const int fill = nk >= 64 ? 512 : 256;
     int s = 1;
-    while (tiles * s < 256 && s * 2 <= 16 && nk / (s * 2) >= 4) s *= 2;   // fill the CUs; keep >= 4 K-steps per split
+    while (tiles * s < fill && s * 2 <= 16 && nk / (s * 2) >= 4) s *= 2;
     return s;
 }
 
