@@ -592,6 +592,26 @@ __global__ __launch_bounds__(256) void k_linear_big_bf16(const BigLaunch L) {
 // 12 LDS fragment reads per 24 MFMAs instead of 9 per 12 -- for launches with enough tiles to fill the CUs that way.
 // LNT: the consumer normalises, as in k_linear_big<., true> -- LayerNorm + SiLU of the X rows between the global load and
 // the split, from the row statistics the producer left behind (a problem without ln_g in the same launch loads as before).
+// four values -> their three bf16 parts (h = bf16(a), m = bf16(a - h), l = bf16(a - h - m)), pairwise: one
+// v_cvt_pk_bf16_f32 per pair and part, the parts widened back by a shift / a mask, residuals as packed fp32 subtractions
+typedef float big_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 big_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int big_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned big_pack2(big_f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, big_bf16x2)); }
+__device__ __forceinline__ big_f32x2 big_widen2(unsigned p) {
+    return big_f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+}
+__device__ __forceinline__ void big_split_put(__bf16* dh, __bf16* dm, __bf16* dl, float f0, float f1, float f2, float f3) {
+    const big_f32x2 x0{f0, f1}, x1{f2, f3};
+    const unsigned h0 = big_pack2(x0), h1 = big_pack2(x1);
+    const big_f32x2 r0 = x0 - big_widen2(h0), r1 = x1 - big_widen2(h1);
+    const unsigned m0 = big_pack2(r0), m1 = big_pack2(r1);
+    const big_f32x2 q0 = r0 - big_widen2(m0), q1 = r1 - big_widen2(m1);
+    *reinterpret_cast<big_u32x2*>(dh) = big_u32x2{h0, h1};
+    *reinterpret_cast<big_u32x2*>(dm) = big_u32x2{m0, m1};
+    *reinterpret_cast<big_u32x2*>(dl) = big_u32x2{big_pack2(q0), big_pack2(q1)};
+}
+
 template <bool PRESPLIT, int NT, bool LNT, int MT = 1>
 __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
     constexpr int BN = 64 * NT, BM = 64 * MT;
@@ -699,20 +719,7 @@ __global__ __launch_bounds__(256) void k_linear_big_split(const BigLaunch L) {
             }                                                               \
         }                                                                   \
     }
-#define BIGS_PUT(S, row, v)                                                 \
-    {                                                                       \
-        const float f[4] = {(v).x, (v).y, (v).z, (v).w};                    \
-        bf16x4 h, m, l;                                                     \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                     \
-            h[c] = (__bf16)f[c];                                            \
-            const float r1 = f[c] - (float)h[c];                            \
-            m[c] = (__bf16)r1;                                              \
-            l[c] = (__bf16)(r1 - (float)m[c]);                              \
-        }                                                                   \
-        *reinterpret_cast<bf16x4*>(&S[0][row][skq]) = h;                    \
-        *reinterpret_cast<bf16x4*>(&S[1][row][skq]) = m;                    \
-        *reinterpret_cast<bf16x4*>(&S[2][row][skq]) = l;                    \
-    }
+#define BIGS_PUT(S, row, v) big_split_put(&S[0][row][skq], &S[1][row][skq], &S[2][row][skq], (v).x, (v).y, (v).z, (v).w);
 #define BIGS_FRAG(S, part, row, half) (*reinterpret_cast<const bf16x8*>(&S[part][row][(half) * 16 + lh * 8]))
 #define BIGS_MMA(a, b, acc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     // smallest partial products first; the two accumulators alternate so that consecutive MFMAs are independent
