@@ -1175,9 +1175,12 @@ static int imagine_enqueue_part(const drm_imagine_weights* w, const drm_imagine_
     const bool big = B >= BIG_MIN_ROWS || wide;
     float* act[3] = {big ? ws + wl.act[0] : nullptr, big ? ws + wl.act[1] : nullptr, big ? ws + wl.act[2] : nullptr};
 
-    // precision 2: three exact bf16 planes per weight; precision 1: one rounded bf16 image (half the weight bytes per step)
+    // precision 1: one rounded bf16 image per weight, made once per call (half the weight bytes per step).  Precision 2
+    // splits the fp32 weights on their way into LDS like the activations: three bf16 planes made up front are 6 bytes per
+    // weight through the vector caches instead of 4, and operand bytes are what these kernels wait for (6.28 -> 6.08 ms per
+    // 4096-trajectory block once the split itself became cheap); DRM_SPLIT_WEIGHT_IMAGES=1 brings the planes back.
     struct ImageScope { ~ImageScope() { big_image_cache_end(); } } image_scope;
-    if (prec != 0 && big && std::getenv("DRM_NO_WEIGHT_IMAGES") == nullptr)
+    if ((prec == 1 || (prec == 2 && std::getenv("DRM_SPLIT_WEIGHT_IMAGES") != nullptr)) && big && std::getenv("DRM_NO_WEIGHT_IMAGES") == nullptr)
         big_image_cache_begin(ws + wl.split, wl.split_floats * sizeof(float), prec == 2 ? 3 : 1);
 
     const bool few = B <= SKINNY_MAX_ROWS && !wide;
