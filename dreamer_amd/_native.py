@@ -143,6 +143,9 @@ SIGNATURES = {
     "drm_fused_linear_bf16": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_fused_linear_split": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "drm_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "drm_gemm_split_f32": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "drm_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_gemm_f32": (C.c_int, [C.c_int32] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -554,6 +557,40 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     check(lib().drm_gemm_f32(int(trans_a), int(trans_b), M, N, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), ptr(bias),
                              c.data_ptr(), c.stride(0), ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(a.device)),
           "drm_gemm_f32")
+    return c
+
+
+def gemm_split_ok(a: torch.Tensor, b: torch.Tensor, trans_a: bool) -> bool:
+    """Whether ``gemm_split`` takes (a, b): fp32 device matrices with contiguous 16-byte aligned rows, b (K, N) with N % 4 == 0,
+    a (K, M) with M % 4 == 0 (trans_a) or (M, K) with K % 32 == 0."""
+    for t in (a, b):
+        if not (t.is_cuda and t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+                and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0):
+            return False
+    if b.shape[1] % 4:
+        return False
+    if trans_a:
+        return a.shape[0] == b.shape[0] and a.shape[1] % 4 == 0
+    return a.shape[1] == b.shape[0] and a.shape[1] % 32 == 0
+
+
+def gemm_split(a: torch.Tensor, b: torch.Tensor, trans_a: bool) -> torch.Tensor:
+    """a.T @ b (trans_a: a is (K, M)) or a @ b (a is (M, K)) with b (K, N): fp32 results on the bf16 matrix pipe (both operands
+    split exactly into three bf16 parts), no transposed copies -- the weight and input gradients of a large Linear layer."""
+    if not gemm_split_ok(a, b, trans_a):
+        raise NativeError("gemm_split: operands must be fp32 device matrices with contiguous, 16-byte aligned rows and matching extents")
+    M = a.shape[1] if trans_a else a.shape[0]
+    K, Nn = b.shape
+    c = torch.empty((M, Nn), dtype=torch.float32, device=a.device)
+    need = lib().drm_gemm_split_workspace_bytes(int(trans_a), M, Nn, K)
+    ws = None
+    if need:
+        held = _gemm_ws.setdefault(a.device, [])
+        if not held or held[-1].numel() * 4 < need:
+            held.append(torch.empty(need // 4 + 4, dtype=torch.float32, device=a.device))
+        ws = held[-1]
+    check(lib().drm_gemm_split_f32(int(trans_a), M, Nn, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
+                                   ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(a.device)), "drm_gemm_split_f32")
     return c
 
 

@@ -35,9 +35,16 @@ struct ConvArgs {
     int NI, Hs, Ws, cs, cb;
     int ksteps_per_split;                              // WGRAD
     float* partial;                                    // WGRAD with splits > 1: (splits, cs, 16 cb)
+    // MAT_TN: S = A (K = NI rows, lda), T = B (K rows, ldb), out (cs = M, cb = N; ldc);  MAT_NT: S = A (NI = M rows, lda),
+    // Q = B (cs = K rows, ldb), out (M, cb = N; ldc)
+    int64_t lda = 0, ldb = 0, ldc = 0;
 };
 
-enum { CONV_DOWN = 0, CONV_UP = 1, CONV_WGRAD = 2 };
+enum { CONV_DOWN = 0, CONV_UP = 1, CONV_WGRAD = 2,
+       // plain matrices on the split kernel's staging (no pixel geometry), for the large Linear gradients whose operands
+       // are not reduction-contiguous: C (M, N) = A^T B with A (K, M), B (K, N) [weight gradient dW = dY^T X], and
+       // C (M, N) = A B with A (M, K), B (K, N) [input gradient dX = dY W]
+       MAT_TN = 3, MAT_NT = 4 };
 
 // An operand tile of R = 64 * RB rows (RB = 1 or 2) by 32 reduction steps; every thread moves 2 * RB f32x4.
 //   [row][k] image: rows (tid >> 3) + 32 i, k offset (tid & 7) * 4, row stride 36 words
@@ -347,8 +354,8 @@ __device__ __forceinline__ void cvs_put(__bf16* dst, int part_stride, float f0, 
 template <int MODE, int MT, int NT, int WN = 2>
 __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     constexpr int BM = 32 * MT * (4 / WN), BN = 32 * NT * WN;
-    constexpr bool A_ROWK = MODE != CONV_WGRAD;     // DOWN / UP: A is [row][k]; WGRAD: A is [k][row]
-    constexpr bool B_ROWK = MODE == CONV_DOWN;      // DOWN: B = Q rows [j][k]; UP / WGRAD: [k][col]
+    constexpr bool A_ROWK = MODE != CONV_WGRAD && MODE != MAT_TN;   // DOWN / UP / NT: A is [row][k]; WGRAD / TN: A is [k][row]
+    constexpr bool B_ROWK = MODE == CONV_DOWN;                      // DOWN: B = Q rows [j][k]; the others: [k][col]
     constexpr int A_KGS = BM, B_KGS = BN, A_PART = cvs_part(BM), B_PART = cvs_part(BN);      // (the macros' KGS = rows of the part)
     constexpr int STAGE_BYTES = 2 * 3 * (A_PART + B_PART), TILE_BYTES = 4 * BM * (BN + 4);
     constexpr int NVB = B_ROWK ? BN / 32 : 4;       // f32x4 per thread and K-step of the B tile (A: 4 either way)
@@ -374,6 +381,10 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { pn[i] = pa[i] = pb[i] = 0; pv[i] = false; }
     int py = 0, px = 0;
+    if (MODE == MAT_NT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = m0 + srow + 32 * i < pixels;
+    }
     if (MODE == CONV_DOWN || MODE == CONV_UP) {
         if (MODE == CONV_UP) { py = blockIdx.z >> 1; px = blockIdx.z & 1; }
 #pragma unroll
@@ -407,6 +418,7 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     int nk, ks0 = 0;
     if (MODE == CONV_DOWN) nk = 16 * cb / CV_BK;
     else if (MODE == CONV_UP) nk = 4 * cs / CV_BK;
+    else if (MODE == MAT_NT) nk = cs / CV_BK;
     else {
         const int nk_all = (pixels + CV_BK - 1) / CV_BK;
         ks0 = blockIdx.z * G.ksteps_per_split;
@@ -437,13 +449,17 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
                 const bool ok = pv[i] && (unsigned)a < (unsigned)Hs && (unsigned)b < (unsigned)Ws;                       \
                 v[i] = *reinterpret_cast<const f32x4*>(ok ? G.S + ((int64_t)(pn[i] * Hs + a) * Ws + b) * cs + s0 : cv_zeros); \
             }                                                                                                            \
+        } else if (MODE == MAT_NT) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+                v[i] = *reinterpret_cast<const f32x4*>(pv[i] ? G.S + (int64_t)(m0 + srow + 32 * i) * G.lda + kst * CV_BK + skq : cv_zeros); \
         } else {                                                                                                         \
             /* S as (pixels, cs): 4 consecutive reduction rows m, the thread's 4 output rows j */                        \
             const int j = m0 + 4 * a_rg;                                                                                 \
+            const int64_t lds_ = MODE == MAT_TN ? G.lda : (int64_t)cs;                                                   \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
                 const int m = (ks0 + kst) * CV_BK + a_kq * 4 + q;                                                        \
                 const bool ok = a_on && m < pixels && j < cs;                                                            \
-                v[q] = *reinterpret_cast<const f32x4*>(ok ? G.S + (int64_t)m * cs + j : cv_zeros);                           \
+                v[q] = *reinterpret_cast<const f32x4*>(ok ? G.S + (int64_t)m * lds_ + j : cv_zeros);                     \
             }                                                                                                            \
         }                                                                                                                \
     }
@@ -466,6 +482,16 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
                 const int s = s0 + b_kq * 4 + q;                                                                         \
                 v[q] = *reinterpret_cast<const f32x4*>(ok ? G.Q + ((int64_t)s * 16 + kh * 4 + kw) * cb + c : cv_zeros);      \
+            }                                                                                                            \
+        } else if (MODE == MAT_TN || MODE == MAT_NT) {                                                                   \
+            /* B as (K, N): 4 consecutive reduction rows, the thread's 4 output columns */                               \
+            const int c = n0 + 4 * b_rg;                                                                                 \
+            const int kmax = MODE == MAT_TN ? pixels : cs;                                                               \
+            const float* const bp = MODE == MAT_TN ? G.T : G.Q;                                                          \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+                const int kr = (ks0 + kst) * CV_BK + b_kq * 4 + q;                                                       \
+                const bool ok = b_on && kr < kmax && c < cb;                                                             \
+                v[q] = *reinterpret_cast<const f32x4*>(ok ? bp + (int64_t)kr * G.ldb + c : cv_zeros);                    \
             }                                                                                                            \
         } else {                                                                                                         \
             const int mb = (ks0 + kst) * CV_BK + b_kq * 4;                                                               \
@@ -560,8 +586,8 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     __syncthreads();
     constexpr int TPR = BN / 4;                 // threads per output row
     const int c4 = (tid % TPR) * 4, col = n0 + c4;
-    const int ncols = MODE == CONV_DOWN ? cs : (MODE == CONV_UP ? cb : 16 * cb);
-    const int nrows = MODE == CONV_WGRAD ? cs : pixels;
+    const int ncols = MODE == CONV_DOWN ? cs : (MODE == CONV_WGRAD ? 16 * cb : cb);
+    const int nrows = (MODE == CONV_WGRAD || MODE == MAT_TN) ? cs : pixels;
     if (col >= ncols) return;
     for (int r = tid / TPR; r < BM; r += 256 / TPR) {
         const int m = m0 + r;
@@ -572,7 +598,9 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
         else if (MODE == CONV_UP) {
             const int n = m / (Hs * Ws), rr = m - n * (Hs * Ws), a = rr / Ws, b = rr - a * Ws;
             o = G.out + ((int64_t)(n * Hb + 2 * a + py) * Wb + 2 * b + px) * cb + col;
-        } else {
+        } else if (MODE == MAT_NT) o = G.out + (int64_t)m * G.ldc + col;
+        else if (MODE == MAT_TN) o = G.partial ? G.partial + ((int64_t)blockIdx.z * cs + m) * cb + col : G.out + (int64_t)m * G.ldc + col;
+        else {
             float* base = G.partial ? G.partial + (int64_t)blockIdx.z * cs * 16 * cb : G.out;
             o = base + (int64_t)m * 16 * cb + col;
         }
@@ -832,6 +860,60 @@ extern "C" int drm_conv4s2_wgrad(const float* small, const float* big, float* ke
         const int64_t blocks = (total4 + 255) / 256;
         ProfScope prof(PC_ELEMENTWISE, s, (double)splits * total4 * 4, 16.0 * (splits + 1.0) * total4);
         k_conv_reduce<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s>>>(g.partial, splits, total4, kernel_grad_out);
+        DRM_LAUNCH_CHECK();
+    }
+    return DRM_OK;
+}
+
+// ---- large Linear gradients on the split kernel's staging ----------------------------------------------------------------
+static int mat_tn_splits(int M, int N, int K) {
+    const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    const int nk = (K + CV_BK - 1) / CV_BK;
+    int s = 1;
+    while (tiles * s < 256 && s * 2 <= 64 && nk / (s * 2) >= 8) s *= 2;
+    return s;
+}
+
+extern "C" size_t drm_gemm_split_workspace_bytes(int32_t trans_a, int32_t M, int32_t N, int32_t K) {
+    if (!trans_a || M < 1 || N < 1 || K < 1) return 0;
+    const int s = mat_tn_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+extern "C" int drm_gemm_split_f32(int32_t trans_a, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, const float* B,
+                                  int64_t ldb, float* C, int64_t ldc, void* workspace, size_t workspace_bytes, drm_stream_t stream) {
+    DRM_REQUIRE(A && B && C, DRM_EINVAL, "null pointer");
+    DRM_REQUIRE(M >= 1 && N >= 4 && K >= 1 && N % 4 == 0 && ldb >= N && ldb % 4 == 0 && ldc >= N && ldc % 4 == 0, DRM_EINVAL,
+                "M=%d N=%d K=%d ldb=%lld ldc=%lld (N and the leading dimensions multiples of 4)", M, N, K, (long long)ldb, (long long)ldc);
+    DRM_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), DRM_EINVAL, "operands must be 16-byte aligned");
+    DRM_REQUIRE((int64_t)M * N < (1ll << 31) && (int64_t)K * (M > N ? M : N) < (1ll << 40), DRM_EINVAL, "extents too large");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(PC_LINEAR_BIG, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    if (trans_a) {                                  // C = A^T B, A (K, M)
+        DRM_REQUIRE(M % 4 == 0 && lda >= M && lda % 4 == 0, DRM_EINVAL, "M=%d and lda=%lld must be multiples of 4", M, (long long)lda);
+        const int splits = mat_tn_splits(M, N, K);
+        const int nk = (K + CV_BK - 1) / CV_BK;
+        ConvArgs g{B, A, nullptr, C, K, 1, 1, M, N, (nk + splits - 1) / splits, nullptr};
+        g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+        if (splits > 1) {
+            const size_t need = (size_t)splits * M * N * sizeof(float);
+            DRM_REQUIRE(workspace && workspace_bytes >= need && aligned16(workspace), DRM_EINVAL, "workspace too small: need %zu bytes", need);
+            DRM_REQUIRE(ldc == N, DRM_EINVAL, "a split reduction writes a contiguous result (ldc = N)");
+            g.partial = (float*)workspace;
+        }
+        k_conv_split<MAT_TN, 2, 2><<<dim3((N + 127) / 128, (M + 127) / 128, splits), dim3(256), 0, s>>>(g);
+        DRM_LAUNCH_CHECK();
+        if (splits > 1) {
+            const int64_t total4 = (int64_t)M * N / 4;
+            const int64_t blocks = (total4 + 255) / 256;
+            k_conv_reduce<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s>>>(g.partial, splits, total4, C);
+            DRM_LAUNCH_CHECK();
+        }
+    } else {                                        // C = A B, A (M, K)
+        DRM_REQUIRE(K % CV_BK == 0 && lda >= K && lda % 4 == 0, DRM_EINVAL, "K=%d must be a multiple of 32, lda=%lld of 4", K, (long long)lda);
+        ConvArgs g{nullptr, A, B, C, M, 1, 1, K, N, 0, nullptr};
+        g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+        k_conv_split<MAT_NT, 2, 2><<<dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, s>>>(g);
         DRM_LAUNCH_CHECK();
     }
     return DRM_OK;

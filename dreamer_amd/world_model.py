@@ -63,6 +63,11 @@ class _bf16_products:
         _PRODUCT_FORM = self.before
 
 
+# the large Linear gradients in the split form read their operands as they lie (the kernel transposes tiles on their way into
+# LDS); DRM_NO_GRADIENT_STAGING=1 goes back to transposed copies and the forward kernel
+_GRADIENT_STAGING = os.environ.get("DRM_NO_GRADIENT_STAGING", "0") != "1"
+
+
 def _large_product(form: str, x, w, b=None):
     from . import _native as N
     return N.fused_linear(x, w, b, bf16=form == "bf16", split=form == "split")
@@ -95,6 +100,8 @@ def _mm_dgrad(dy, w, form="f32"):
     """dy @ w: the input gradient of a Linear with weight w (out, in)."""
     from . import _native as N
     if form != "f32" and dy.is_cuda and dy.dtype == torch.float32 and dy.stride(1) == 1 and _large_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
+        if form == "split" and _GRADIENT_STAGING and N.gemm_split_ok(dy, w, False):
+            return N.gemm_split(dy, w, False)                     # w read as it lies, (out, in) = (K, N)
         return _large_product(form, dy, w.t().contiguous())       # the reduction runs over w's rows: transposed once
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, w, False, True):
         return N.gemm(dy, w, False, True)
@@ -105,6 +112,8 @@ def _mm_wgrad(dy, x, form="f32"):
     """dy.T @ x: the weight gradient of a Linear, a sum over the rows."""
     from . import _native as N
     if form != "f32" and dy.is_cuda and dy.dtype == torch.float32 and _large_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
+        if form == "split" and _GRADIENT_STAGING and N.gemm_split_ok(dy, x, True):
+            return N.gemm_split(dy, x, True)                      # both operands read as they lie, rows = the reduction
         return _large_product(form, dy.t().contiguous(), x.t().contiguous())   # the sum over the rows along memory
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, x, True, True):
         return N.gemm(dy, x, True, True)

@@ -251,6 +251,18 @@ int drm_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t
                  const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, void* workspace,
                  size_t workspace_bytes, drm_stream_t stream);
 
+/* The two gradient products of a large nn.Linear (lib/world_model.py:153-160, :283-288: what autograd computes for it)
+ * whose operands do not have the reduction index contiguous in memory, on the bf16 matrix pipe with both operands split
+ * exactly into three bf16 parts (fp32 results, as drm_fused_linear_split), without transposed copies of the operands:
+ *   trans_a = 1:  C (M, N) = A^T B,  A (K, M), B (K, N)   -- weight gradient dW = dY^T X
+ *   trans_a = 0:  C (M, N) = A B,    A (M, K), B (K, N)   -- input gradient dX = dY W     (K % 32 == 0)
+ * N, lda, ldb, ldc multiples of 4 (M too for trans_a = 1), 16-byte aligned.  With few output tiles the reduction of the
+ * trans_a = 1 form is split over workgroups into `workspace` (drm_gemm_split_workspace_bytes, may be 0; then ldc = N)
+ * and summed in a fixed order. */
+size_t drm_gemm_split_workspace_bytes(int32_t trans_a, int32_t M, int32_t N, int32_t K);
+int drm_gemm_split_f32(int32_t trans_a, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, const float* B,
+                       int64_t ldb, float* C, int64_t ldc, void* workspace, size_t workspace_bytes, drm_stream_t stream);
+
 /* Column sums of a row-major fp32 matrix, out[c] = sum_r x[r, c], rows added in a fixed order: the bias gradient autograd
  * forms for nn.Linear (lib/world_model.py:153-160 etc.: grad_bias = grad_output.sum(0)) and the sum over the slices of
  * the LayerNorm parameter-gradient partials (drm_ln_silu_backward).  cols and ldx multiples of 4, 16-byte aligned. */

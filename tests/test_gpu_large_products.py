@@ -5,6 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from dreamer_amd import _native as N
 from dreamer_amd import world_model as W
 
 pytestmark = pytest.mark.gpu
@@ -65,3 +66,18 @@ def test_linear_norm_act_block_in_every_form(form, tol):
     out = _run(form, lambda *t: W._LinearNormActFn.apply(*t, 1e-5), x, w, b, ga, be, dy)
     for name, a, r in zip(("y", "dx", "dw", "db", "dgamma", "dbeta"), out, (ref.detach(), *ref_g)):
         assert _rel(a, r) < tol, (form, name, _rel(a, r))
+
+
+@pytest.mark.parametrize("M,Nn,K,ta", [(4096, 1536, 1024, True), (1024, 4096, 1024, True), (1024, 4096, 1024, False), (132, 260, 96, True),
+                                       (70, 36, 64, False), (8, 4, 5, True), (300, 516, 1000, True), (257, 388, 32, False)])
+def test_gradient_products_without_transposed_copies(M, Nn, K, ta):
+    """dW = dY^T X and dX = dY W on the split kernel's staging against fp64: full tiles, ragged tiles, a split reduction."""
+    g = torch.Generator().manual_seed(M + Nn + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    b = torch.randn(K, Nn, generator=g).to(DEV)
+    assert N.gemm_split_ok(a, b, ta)
+    got = N.gemm_split(a, b, ta)
+    ref = (a.double().t() if ta else a.double()) @ b.double()
+    assert got.shape == (M, Nn)
+    assert float((got.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max()) * max(1.0, (K / 1024) ** 0.5)
+    assert torch.equal(got, N.gemm_split(a, b, ta))      # fixed-order reduction
