@@ -130,6 +130,9 @@ SIGNATURES = {
     "drm_conv_img_up": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv_img_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int32] * 4),
     "drm_conv_img_wgrad": (C.c_int, [C.c_void_p] * 4 + [C.c_size_t, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
+    "drm_conv4s2_down_prec": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]),
+    "drm_conv4s2_up_prec": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 5 + [C.c_void_p]),
+    "drm_conv4s2_wgrad_prec": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "drm_conv4s2_down": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_up": (C.c_int, [C.c_void_p] * 3 + [C.c_int64] + [C.c_int32] * 4 + [C.c_void_p]),
     "drm_conv4s2_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64] + [C.c_int32] * 4),
@@ -144,7 +147,7 @@ SIGNATURES = {
     "drm_fused_linear_split": (C.c_int, [C.POINTER(drm_linear_args), C.c_void_p]),
     "drm_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "drm_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
-    "drm_gemm_split_f32": (C.c_int, [C.c_int32] * 4 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+    "drm_gemm_split_f32": (C.c_int, [C.c_int32] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
     "drm_colsum_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "drm_gemm_f32": (C.c_int, [C.c_int32] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
@@ -574,9 +577,10 @@ def gemm_split_ok(a: torch.Tensor, b: torch.Tensor, trans_a: bool) -> bool:
     return a.shape[1] == b.shape[0] and a.shape[1] % 32 == 0
 
 
-def gemm_split(a: torch.Tensor, b: torch.Tensor, trans_a: bool) -> torch.Tensor:
+def gemm_split(a: torch.Tensor, b: torch.Tensor, trans_a: bool, bf16: bool = False) -> torch.Tensor:
     """a.T @ b (trans_a: a is (K, M)) or a @ b (a is (M, K)) with b (K, N): fp32 results on the bf16 matrix pipe (both operands
-    split exactly into three bf16 parts), no transposed copies -- the weight and input gradients of a large Linear layer."""
+    split exactly into three bf16 parts; ``bf16``: rounded to bf16 instead), no transposed copies -- the weight and input gradients
+    of a large Linear layer."""
     if not gemm_split_ok(a, b, trans_a):
         raise NativeError("gemm_split: operands must be fp32 device matrices with contiguous, 16-byte aligned rows and matching extents")
     M = a.shape[1] if trans_a else a.shape[0]
@@ -589,7 +593,7 @@ def gemm_split(a: torch.Tensor, b: torch.Tensor, trans_a: bool) -> torch.Tensor:
         if not held or held[-1].numel() * 4 < need:
             held.append(torch.empty(need // 4 + 4, dtype=torch.float32, device=a.device))
         ws = held[-1]
-    check(lib().drm_gemm_split_f32(int(trans_a), M, Nn, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
+    check(lib().drm_gemm_split_f32(int(trans_a), int(bool(bf16)), M, Nn, K, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
                                    ptr(ws), 0 if ws is None else ws.numel() * 4, stream_ptr(a.device)), "drm_gemm_split_f32")
     return c
 
@@ -629,7 +633,7 @@ def conv4s2_ok(cs: int, cb: int, mode: str) -> bool:
     return {"down": cb % 32 == 0, "up": cs % 32 == 0, "wgrad": True}[mode]
 
 
-def conv4s2_down(big: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+def conv4s2_down(big: torch.Tensor, kernel: torch.Tensor, bf16: bool = False) -> torch.Tensor:
     """conv2d(big, kernel, stride 2, padding 1) for kernel (cs, cb, 4, 4); channels-last in and out."""
     big, kernel = _cl4(big, "big"), _cl4(kernel, "kernel")
     ni, cb, hb, wb = big.shape
@@ -637,12 +641,12 @@ def conv4s2_down(big: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     if tuple(kernel.shape) != (cs, cb, 4, 4) or hb % 2 or wb % 2:
         raise NativeError(f"conv4s2_down: kernel {tuple(kernel.shape)} does not fit an input of shape {tuple(big.shape)} (even height and width)")
     out = torch.empty((ni, cs, hb // 2, wb // 2), dtype=torch.float32, device=big.device, memory_format=torch.channels_last)
-    check(lib().drm_conv4s2_down(big.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hb // 2, wb // 2, cs, cb,
-                                 stream_ptr(big.device)), "drm_conv4s2_down")
+    check(lib().drm_conv4s2_down_prec(big.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hb // 2, wb // 2, cs, cb, int(bool(bf16)),
+                                      stream_ptr(big.device)), "drm_conv4s2_down")
     return out
 
 
-def conv4s2_up(small: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+def conv4s2_up(small: torch.Tensor, kernel: torch.Tensor, bf16: bool = False) -> torch.Tensor:
     """conv_transpose2d(small, kernel, stride 2, padding 1) for kernel (cs, cb, 4, 4); channels-last in and out."""
     small, kernel = _cl4(small, "small"), _cl4(kernel, "kernel")
     ni, cs, hs, ws = small.shape
@@ -650,12 +654,12 @@ def conv4s2_up(small: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     if tuple(kernel.shape) != (cs, cb, 4, 4):
         raise NativeError(f"conv4s2_up: kernel {tuple(kernel.shape)} does not fit an input of shape {tuple(small.shape)}")
     out = torch.empty((ni, cb, 2 * hs, 2 * ws), dtype=torch.float32, device=small.device, memory_format=torch.channels_last)
-    check(lib().drm_conv4s2_up(small.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, stream_ptr(small.device)),
-          "drm_conv4s2_up")
+    check(lib().drm_conv4s2_up_prec(small.data_ptr(), kernel.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, int(bool(bf16)),
+                                    stream_ptr(small.device)), "drm_conv4s2_up")
     return out
 
 
-def conv4s2_wgrad(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
+def conv4s2_wgrad(small: torch.Tensor, big: torch.Tensor, bf16: bool = False) -> torch.Tensor:
     """Kernel gradient (cs, cb, 4, 4) (channels-last memory) of a stride-2 4x4 layer from its small- and big-resolution
     tensors: for a convolution (big -> small) pass (grad_output, input), for a transposed one (input, grad_output)."""
     small, big = _cl4(small, "small"), _cl4(big, "big")
@@ -671,8 +675,9 @@ def conv4s2_wgrad(small: torch.Tensor, big: torch.Tensor) -> torch.Tensor:
         if not held or held[-1].numel() * 4 < need:
             held.append(torch.empty(need // 4 + 4, dtype=torch.float32, device=small.device))
         ws_t = held[-1]
-    check(lib().drm_conv4s2_wgrad(small.data_ptr(), big.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, ptr(ws_t),
-                                  0 if ws_t is None else ws_t.numel() * 4, stream_ptr(small.device)), "drm_conv4s2_wgrad")
+    check(lib().drm_conv4s2_wgrad_prec(small.data_ptr(), big.data_ptr(), out.data_ptr(), ni, hs, ws, cs, cb, ptr(ws_t),
+                                       0 if ws_t is None else ws_t.numel() * 4, int(bool(bf16)), stream_ptr(small.device)),
+          "drm_conv4s2_wgrad")
     return out
 
 

@@ -351,18 +351,26 @@ __device__ __forceinline__ void cvs_put(__bf16* dst, int part_stride, float f0, 
     *reinterpret_cast<cv_u32x2*>(dst + 2 * part_stride) = cv_u32x2{cvs_pack(q0), cvs_pack(q1)};
 }
 
-template <int MODE, int MT, int NT, int WN = 2>
+// PARTS = 1: the operands rounded to bf16 (their first part only) -- a bf16-input product with fp32 accumulation, one
+// MFMA where the exact form has six, a third of the LDS image
+template <int PARTS>
+__device__ __forceinline__ void cvs_putp(__bf16* dst, int part_stride, float f0, float f1, float f2, float f3) {
+    if (PARTS == 3) cvs_put(dst, part_stride, f0, f1, f2, f3);
+    else *reinterpret_cast<cv_u32x2*>(dst) = cv_u32x2{cvs_pack(cv_f32x2{f0, f1}), cvs_pack(cv_f32x2{f2, f3})};
+}
+
+template <int MODE, int MT, int NT, int WN = 2, int PARTS = 3>
 __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     constexpr int BM = 32 * MT * (4 / WN), BN = 32 * NT * WN;
     constexpr bool A_ROWK = MODE != CONV_WGRAD && MODE != MAT_TN;   // DOWN / UP / NT: A is [row][k]; WGRAD / TN: A is [k][row]
     constexpr bool B_ROWK = MODE == CONV_DOWN;                      // DOWN: B = Q rows [j][k]; the others: [k][col]
     constexpr int A_KGS = BM, B_KGS = BN, A_PART = cvs_part(BM), B_PART = cvs_part(BN);      // (the macros' KGS = rows of the part)
-    constexpr int STAGE_BYTES = 2 * 3 * (A_PART + B_PART), TILE_BYTES = 4 * BM * (BN + 4);
+    constexpr int STAGE_BYTES = 2 * PARTS * (A_PART + B_PART), TILE_BYTES = 4 * BM * (BN + 4);
     constexpr int NVB = B_ROWK ? BN / 32 : 4;       // f32x4 per thread and K-step of the B tile (A: 4 either way)
     static_assert(A_ROWK ? BM == 128 : true, "pixel-row tiles are 128 rows");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
     __bf16* const sA = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* const sB = sA + 3 * A_PART;
+    __bf16* const sB = sA + PARTS * A_PART;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = WN == 2 ? (wave & 1) : wave, wn = WN == 2 ? (wave >> 1) : 0, li = lane & 31, lh = lane >> 5;
     const int Hs = G.Hs, Ws = G.Ws, cs = G.cs, cb = G.cb, Hb = 2 * Hs, Wb = 2 * Ws;
@@ -510,14 +518,14 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
     // registers -> LDS, split on the way
 #define CS_PUT_ROWK(S, KGS, PART, v, NV)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < NV; ++i)                                                                       \
-        cvs_put(S + cvs_kgo(KGS, skq >> 3) + (srow + 32 * i) * 8 + (skq & 7), PART, v[i].x, v[i].y, v[i].z, v[i].w);
+        cvs_putp<PARTS>(S + cvs_kgo(KGS, skq >> 3) + (srow + 32 * i) * 8 + (skq & 7), PART, v[i].x, v[i].y, v[i].z, v[i].w);
 #define CS_PUT_KROW(S, KGS, PART, R, rg, kq, on, v)                                                                      \
     if (on) {                                                                                                            \
         __bf16* const d_ = S + cvs_kgo(KGS, kq >> 1) + rg * 8 + (kq & 1) * 4;                                            \
-        cvs_put(d_, PART, v[0].x, v[1].x, v[2].x, v[3].x);                                                               \
-        cvs_put(d_ + (R / 4) * 8, PART, v[0].y, v[1].y, v[2].y, v[3].y);                                                 \
-        cvs_put(d_ + 2 * (R / 4) * 8, PART, v[0].z, v[1].z, v[2].z, v[3].z);                                             \
-        cvs_put(d_ + 3 * (R / 4) * 8, PART, v[0].w, v[1].w, v[2].w, v[3].w);                                             \
+        cvs_putp<PARTS>(d_, PART, v[0].x, v[1].x, v[2].x, v[3].x);                                                               \
+        cvs_putp<PARTS>(d_ + (R / 4) * 8, PART, v[0].y, v[1].y, v[2].y, v[3].y);                                                 \
+        cvs_putp<PARTS>(d_ + 2 * (R / 4) * 8, PART, v[0].z, v[1].z, v[2].z, v[3].z);                                             \
+        cvs_putp<PARTS>(d_ + 3 * (R / 4) * 8, PART, v[0].w, v[1].w, v[2].w, v[3].w);                                             \
     }
 #define CS_FRAG(S, KGS, PART, part, slot, half) \
     (*reinterpret_cast<const cv_bf16x8*>(S + (part) * PART + cvs_kgo(KGS, 2 * (half) + lh) + (slot) * 8))
@@ -542,12 +550,12 @@ __global__ __launch_bounds__(256) void k_conv_split(const ConvArgs G) {
         __syncthreads();                                                                                                 \
         CS_LOAD_A(av, (ks_) + 2) CS_LOAD_B(bv, (ks_) + 2)                                                                          \
         _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                         \
-            cv_bf16x8 fa[MT][3], fb[NT][3];                                                                              \
+            cv_bf16x8 fa[MT][PARTS], fb[NT][PARTS];                                                                      \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) fa[i][p] = CS_FRAG(sA, A_KGS, A_PART, p, wm * 32 * MT + 32 * i + li, half); \
+                _Pragma("unroll") for (int p = 0; p < PARTS; ++p) fa[i][p] = CS_FRAG(sA, A_KGS, A_PART, p, wm * 32 * MT + 32 * i + li, half); \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                               \
-                _Pragma("unroll") for (int p = 0; p < 3; ++p) fb[j][p] = CS_FRAG(sB, B_KGS, B_PART, p, wn * 32 * NT + 32 * j + li, half); \
-            _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                              \
+                _Pragma("unroll") for (int p = 0; p < PARTS; ++p) fb[j][p] = CS_FRAG(sB, B_KGS, B_PART, p, wn * 32 * NT + 32 * j + li, half); \
+            _Pragma("unroll") for (int t = (PARTS == 3 ? 0 : 5); t < 6; ++t) {                                           \
                 constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};                                    \
                 _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                           \
                     _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
@@ -782,15 +790,26 @@ static int check_conv(const void* a, const void* b, const void* out, int64_t NI,
     return DRM_OK;
 }
 
+extern "C" int drm_conv4s2_down_prec(const float* big, const float* kernel, float* small_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                     int32_t cs, int32_t cb, int32_t precision, drm_stream_t stream);
 extern "C" int drm_conv4s2_down(const float* big, const float* kernel, float* small_out, int64_t NI, int32_t Hs, int32_t Ws,
                                 int32_t cs, int32_t cb, drm_stream_t stream) {
+    return drm_conv4s2_down_prec(big, kernel, small_out, NI, Hs, Ws, cs, cb, 0, stream);
+}
+
+// precision 0: fp32 results (split form, or the fp32 MFMA form under DRM_NO_SPLIT_PRODUCTS); 1: operands rounded to bf16
+extern "C" int drm_conv4s2_down_prec(const float* big, const float* kernel, float* small_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                     int32_t cs, int32_t cb, int32_t precision, drm_stream_t stream) {
     if (int rc = check_conv(big, kernel, small_out, NI, Hs, Ws, cs, cb)) return rc;
     DRM_REQUIRE(cb % 32 == 0, DRM_ENOTSUP, "big-resolution channel count %d must be a multiple of 32", cb);
     ConvArgs g{big, nullptr, kernel, small_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
     const int64_t pixels = NI * Hs * Ws;
     ProfScope prof(PC_LINEAR_BIG, (hipStream_t)stream, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
     const dim3 wide(cs / 128, (unsigned)((pixels + 127) / 128), 1), narrow((cs + 63) / 64, (unsigned)((pixels + 127) / 128), 1);
-    if (conv_split_form()) {
+    if (precision == 1) {
+        if (conv_wide_tiles(cs)) k_conv_split<CONV_DOWN, 2, 2, 2, 1><<<wide, dim3(256), 0, (hipStream_t)stream>>>(g);
+        else k_conv_split<CONV_DOWN, 2, 1, 2, 1><<<narrow, dim3(256), 0, (hipStream_t)stream>>>(g);
+    } else if (conv_split_form()) {
         if (conv_wide_tiles(cs)) k_conv_split<CONV_DOWN, 2, 2><<<wide, dim3(256), 0, (hipStream_t)stream>>>(g);
         else k_conv_split<CONV_DOWN, 2, 1><<<narrow, dim3(256), 0, (hipStream_t)stream>>>(g);
     } else if (conv_wide_tiles(cs))
@@ -801,8 +820,15 @@ extern "C" int drm_conv4s2_down(const float* big, const float* kernel, float* sm
     return DRM_OK;
 }
 
+extern "C" int drm_conv4s2_up_prec(const float* small, const float* kernel, float* big_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                   int32_t cs, int32_t cb, int32_t precision, drm_stream_t stream);
 extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* big_out, int64_t NI, int32_t Hs, int32_t Ws,
                               int32_t cs, int32_t cb, drm_stream_t stream) {
+    return drm_conv4s2_up_prec(small, kernel, big_out, NI, Hs, Ws, cs, cb, 0, stream);
+}
+
+extern "C" int drm_conv4s2_up_prec(const float* small, const float* kernel, float* big_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                   int32_t cs, int32_t cb, int32_t precision, drm_stream_t stream) {
     if (int rc = check_conv(small, kernel, big_out, NI, Hs, Ws, cs, cb)) return rc;
     DRM_REQUIRE(cs % 32 == 0, DRM_ENOTSUP, "small-resolution channel count %d must be a multiple of 32", cs);
     ConvArgs g{nullptr, small, kernel, big_out, (int)NI, Hs, Ws, cs, cb, 0, nullptr};
@@ -811,7 +837,10 @@ extern "C" int drm_conv4s2_up(const float* small, const float* kernel, float* bi
     const unsigned mtiles = (unsigned)((pixels + 127) / 128);
     // outputs of 32 columns: all four parity classes per workgroup (class by class a 128 x 32 tile has too few MFMAs per
     // staged value to pay for splitting it: 266 against 252 us of the fp32 form)
-    if (conv_split_form() && cb <= 32 && std::getenv("DRM_CONV_NO_UP4") == nullptr)
+    if (precision == 1 && cb > 32) {
+        if (conv_wide_tiles(cb)) k_conv_split<CONV_UP, 2, 2, 2, 1><<<dim3(cb / 128, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+        else k_conv_split<CONV_UP, 2, 1, 2, 1><<<dim3((cb + 63) / 64, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    } else if (conv_split_form() && cb <= 32 && std::getenv("DRM_CONV_NO_UP4") == nullptr)
         k_conv_up4_split<<<dim3(mtiles), dim3(256), 0, (hipStream_t)stream>>>(g);
     else if (conv_split_form() && cb > 32) {
         if (conv_wide_tiles(cb)) k_conv_split<CONV_UP, 2, 2><<<dim3(cb / 128, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
@@ -833,8 +862,17 @@ extern "C" size_t drm_conv4s2_wgrad_workspace_bytes(int64_t NI, int32_t Hs, int3
     return s > 1 ? (size_t)s * cs * 16 * cb * sizeof(float) : 0;
 }
 
+extern "C" int drm_conv4s2_wgrad_prec(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                      int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, int32_t precision,
+                                      drm_stream_t stream);
 extern "C" int drm_conv4s2_wgrad(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
                                  int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, drm_stream_t stream) {
+    return drm_conv4s2_wgrad_prec(small, big, kernel_grad_out, NI, Hs, Ws, cs, cb, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int drm_conv4s2_wgrad_prec(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
+                                      int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, int32_t precision,
+                                      drm_stream_t stream) {
     if (int rc = check_conv(small, big, kernel_grad_out, NI, Hs, Ws, cs, cb)) return rc;
     const int64_t pixels = NI * Hs * Ws;
     const int splits = wgrad_splits(pixels, cs, cb);
@@ -848,7 +886,10 @@ extern "C" int drm_conv4s2_wgrad(const float* small, const float* big, float* ke
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(PC_LINEAR_BIG, s, 2.0 * pixels * cs * 16 * cb, 4.0 * (4.0 * pixels * cb + 16.0 * cs * cb + (double)pixels * cs));
-        if (conv_split_form()) {
+        if (precision == 1 && conv_split_form()) {       // (same slices as the split form: the workspace size does not depend on the precision)
+            if (conv_wide_tiles(cs)) k_conv_split<CONV_WGRAD, 2, 2, 2, 1><<<dim3((16 * cb + 127) / 128, cs / 128, splits), dim3(256), 0, s>>>(g);
+            else k_conv_split<CONV_WGRAD, 1, 2, 2, 1><<<dim3((16 * cb + 127) / 128, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
+        } else if (conv_split_form()) {
             if (conv_wide_tiles(cs)) k_conv_split<CONV_WGRAD, 2, 2><<<dim3((16 * cb + 127) / 128, cs / 128, splits), dim3(256), 0, s>>>(g);
             else k_conv_split<CONV_WGRAD, 1, 2><<<dim3((16 * cb + 127) / 128, (cs + 63) / 64, splits), dim3(256), 0, s>>>(g);
         } else if (conv_wide_tiles(cs)) k_conv_gemm<CONV_WGRAD, 2, 2><<<dim3((16 * cb + 127) / 128, cs / 128, splits), dim3(256), 0, s>>>(g);
@@ -880,8 +921,9 @@ extern "C" size_t drm_gemm_split_workspace_bytes(int32_t trans_a, int32_t M, int
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
-extern "C" int drm_gemm_split_f32(int32_t trans_a, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, const float* B,
-                                  int64_t ldb, float* C, int64_t ldc, void* workspace, size_t workspace_bytes, drm_stream_t stream) {
+extern "C" int drm_gemm_split_f32(int32_t trans_a, int32_t bf16_inputs, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda,
+                                  const float* B, int64_t ldb, float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
+                                  drm_stream_t stream) {
     DRM_REQUIRE(A && B && C, DRM_EINVAL, "null pointer");
     DRM_REQUIRE(M >= 1 && N >= 4 && K >= 1 && N % 4 == 0 && ldb >= N && ldb % 4 == 0 && ldc >= N && ldc % 4 == 0, DRM_EINVAL,
                 "M=%d N=%d K=%d ldb=%lld ldc=%lld (N and the leading dimensions multiples of 4)", M, N, K, (long long)ldb, (long long)ldc);
@@ -901,7 +943,8 @@ extern "C" int drm_gemm_split_f32(int32_t trans_a, int32_t M, int32_t N, int32_t
             DRM_REQUIRE(ldc == N, DRM_EINVAL, "a split reduction writes a contiguous result (ldc = N)");
             g.partial = (float*)workspace;
         }
-        k_conv_split<MAT_TN, 2, 2><<<dim3((N + 127) / 128, (M + 127) / 128, splits), dim3(256), 0, s>>>(g);
+        if (bf16_inputs) k_conv_split<MAT_TN, 2, 2, 2, 1><<<dim3((N + 127) / 128, (M + 127) / 128, splits), dim3(256), 0, s>>>(g);
+        else k_conv_split<MAT_TN, 2, 2><<<dim3((N + 127) / 128, (M + 127) / 128, splits), dim3(256), 0, s>>>(g);
         DRM_LAUNCH_CHECK();
         if (splits > 1) {
             const int64_t total4 = (int64_t)M * N / 4;
@@ -913,7 +956,8 @@ extern "C" int drm_gemm_split_f32(int32_t trans_a, int32_t M, int32_t N, int32_t
         DRM_REQUIRE(K % CV_BK == 0 && lda >= K && lda % 4 == 0, DRM_EINVAL, "K=%d must be a multiple of 32, lda=%lld of 4", K, (long long)lda);
         ConvArgs g{nullptr, A, B, C, M, 1, 1, K, N, 0, nullptr};
         g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-        k_conv_split<MAT_NT, 2, 2><<<dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, s>>>(g);
+        if (bf16_inputs) k_conv_split<MAT_NT, 2, 2, 2, 1><<<dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, s>>>(g);
+        else k_conv_split<MAT_NT, 2, 2><<<dim3((N + 127) / 128, (M + 127) / 128, 1), dim3(256), 0, s>>>(g);
         DRM_LAUNCH_CHECK();
     }
     return DRM_OK;

@@ -50,9 +50,13 @@ def _wgrad_bf16_ok(dy, D):
 
 
 def _wgrad_bf16(dy, x):
-    """dy.T @ x with bf16 matrix inputs and fp32 accumulation: both operands transposed once so that the sum over the
-    rows runs along contiguous memory, then one launch of the large-row kernel (output rows = columns of dy)."""
+    """dy.T @ x with bf16 matrix inputs and fp32 accumulation: the operands read as they lie by the staging kernel (tiles
+    transposed on their way into LDS); otherwise both transposed once so that the sum over the rows runs along contiguous
+    memory, then one launch of the large-row kernel (output rows = columns of dy)."""
     from . import _native as N
+    from . import world_model as W
+    if W._GRADIENT_STAGING and N.gemm_split_ok(dy, x, True):
+        return N.gemm_split(dy, x, True, bf16=True)
     return N.fused_linear(dy.t().contiguous(), x.t().contiguous(), bf16=True)
 
 

@@ -100,8 +100,8 @@ def _mm_dgrad(dy, w, form="f32"):
     """dy @ w: the input gradient of a Linear with weight w (out, in)."""
     from . import _native as N
     if form != "f32" and dy.is_cuda and dy.dtype == torch.float32 and dy.stride(1) == 1 and _large_product_ok(dy.shape[0], w.shape[1], dy.shape[1]):
-        if form == "split" and _GRADIENT_STAGING and N.gemm_split_ok(dy, w, False):
-            return N.gemm_split(dy, w, False)                     # w read as it lies, (out, in) = (K, N)
+        if form in ("split", "bf16") and _GRADIENT_STAGING and N.gemm_split_ok(dy, w, False):
+            return N.gemm_split(dy, w, False, bf16=form == "bf16")    # w read as it lies, (out, in) = (K, N)
         return _large_product(form, dy, w.t().contiguous())       # the reduction runs over w's rows: transposed once
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, w, False, True):
         return N.gemm(dy, w, False, True)
@@ -112,8 +112,8 @@ def _mm_wgrad(dy, x, form="f32"):
     """dy.T @ x: the weight gradient of a Linear, a sum over the rows."""
     from . import _native as N
     if form != "f32" and dy.is_cuda and dy.dtype == torch.float32 and _large_product_ok(dy.shape[1], x.shape[1], dy.shape[0]):
-        if form == "split" and _GRADIENT_STAGING and N.gemm_split_ok(dy, x, True):
-            return N.gemm_split(dy, x, True)                      # both operands read as they lie, rows = the reduction
+        if form in ("split", "bf16") and _GRADIENT_STAGING and N.gemm_split_ok(dy, x, True):
+            return N.gemm_split(dy, x, True, bf16=form == "bf16")     # both operands read as they lie, rows = the reduction
         return _large_product(form, dy.t().contiguous(), x.t().contiguous())   # the sum over the rows along memory
     if dy.shape[0] >= NATIVE_GEMM_MIN_ROWS and N.gemm_ok(dy, x, True, True):
         return N.gemm(dy, x, True, True)
@@ -356,7 +356,8 @@ class _Conv4s2Fn(torch.autograd.Function):
         from . import _native as N
         ctx.save_for_backward(x, weight)
         ctx.up = up
-        return N.conv4s2_up(x, weight) if up else N.conv4s2_down(x, weight)
+        ctx.bf16 = _PRODUCT_FORM == "bf16"       # inside WorldModel.loss of a model whose update takes bf16 matrix inputs
+        return N.conv4s2_up(x, weight, ctx.bf16) if up else N.conv4s2_down(x, weight, ctx.bf16)
 
     @staticmethod
     def backward(ctx, g):
@@ -365,14 +366,14 @@ class _Conv4s2Fn(torch.autograd.Function):
         gx = gw = None
         if ctx.up:
             if ctx.needs_input_grad[0]:
-                gx = N.conv4s2_down(g, weight)
+                gx = N.conv4s2_down(g, weight, ctx.bf16)
             if ctx.needs_input_grad[1]:
-                gw = N.conv4s2_wgrad(x, g)
+                gw = N.conv4s2_wgrad(x, g, ctx.bf16)
         else:
             if ctx.needs_input_grad[0]:
-                gx = N.conv4s2_up(g, weight)
+                gx = N.conv4s2_up(g, weight, ctx.bf16)
             if ctx.needs_input_grad[1]:
-                gw = N.conv4s2_wgrad(g, x)
+                gw = N.conv4s2_wgrad(g, x, ctx.bf16)
         return gx, gw, None
 
 
@@ -720,10 +721,11 @@ class WorldModel(nn.Module):
         """World-model loss over a (B, T) batch; same value and gradients as lib/world_model.py:530-603."""
         B, T = obs.shape[:2]
         L, K = self.num_latents, self.classes_per_latent
-        h, z, post, last = self.observe(obs, actions, continues, init_state, noise)
-        hf, zf = h.reshape(B * T, -1), z.reshape(B * T, L, K)
-        # a wide model whose scan takes bf16 matrix inputs: the large batched Linear products of the heads as well
+        # a wide model whose scan takes bf16 matrix inputs: the towers' convolutions and the large batched Linear products of
+        # the heads as well
         with _bf16_products(getattr(self, "observe_precision", "f32") == "bf16" and self.hidden_size > 512):
+            h, z, post, last = self.observe(obs, actions, continues, init_state, noise)
+            hf, zf = h.reshape(B * T, -1), z.reshape(B * T, L, K)
             return self._loss_from_states(obs, rewards, continues, h, z, post, last, hf, zf)
 
     def _loss_from_states(self, obs, rewards, continues, h, z, post, last, hf, zf):

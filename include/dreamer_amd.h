@@ -166,7 +166,7 @@ size_t drm_conv_img_wgrad_workspace_bytes(int64_t N, int32_t Cs, int32_t Cimg, i
 int drm_conv_img_wgrad(const float* small_in, const float* big, float* grad_weight, void* workspace, size_t workspace_bytes,
                        int64_t N, int32_t Cs, int32_t Cimg, int32_t H, int32_t W, drm_stream_t stream);
 
-/* ---- stride-2 4x4 convolutions of the towers as implicit fp32 MFMA products, channels-last activations ----------
+/* ---- stride-2 4x4 convolutions of the towers as implicit matrix products, channels-last activations -------------
  * nn.Conv2d(cb -> cs, kernel 4, stride 2, padding 1) (lib/world_model.py:94-108) and nn.ConvTranspose2d(cs -> cb, kernel 4,
  * stride 2, padding 1) (lib/world_model.py:290-302), without bias (the bias is applied by the fused LayerNorm + SiLU that
  * follows).  `big` is (NI, 2 Hs, 2 Ws, cb), `small` is (NI, Hs, Ws, cs), both dense channels-last; `kernel` is
@@ -183,6 +183,16 @@ int drm_conv4s2_up(const float* small, const float* kernel, float* big_out, int6
 size_t drm_conv4s2_wgrad_workspace_bytes(int64_t NI, int32_t Hs, int32_t Ws, int32_t cs, int32_t cb);
 int drm_conv4s2_wgrad(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
                       int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, drm_stream_t stream);
+/* The same three products with a precision argument: 0 = fp32 results (what the calls above give: both operands split
+ * exactly into three bf16 parts on the bf16 matrix pipe, or v_mfma_f32_32x32x2_f32 under DRM_NO_SPLIT_PRODUCTS=1);
+ * 1 = operands rounded to bf16, fp32 accumulation (the towers of a model whose update runs with bf16 matrix inputs). */
+int drm_conv4s2_down_prec(const float* big, const float* kernel, float* small_out, int64_t NI, int32_t Hs, int32_t Ws,
+                          int32_t cs, int32_t cb, int32_t precision, drm_stream_t stream);
+int drm_conv4s2_up_prec(const float* small, const float* kernel, float* big_out, int64_t NI, int32_t Hs, int32_t Ws,
+                        int32_t cs, int32_t cb, int32_t precision, drm_stream_t stream);
+int drm_conv4s2_wgrad_prec(const float* small, const float* big, float* kernel_grad_out, int64_t NI, int32_t Hs, int32_t Ws,
+                           int32_t cs, int32_t cb, void* workspace, size_t workspace_bytes, int32_t precision,
+                           drm_stream_t stream);
 
 /* Optimiser step on flat buffers: global-norm clip (torch.nn.utils.clip_grad_norm_, coefficient
  * min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clip) followed by Adam without weight decay, the
@@ -258,10 +268,12 @@ int drm_gemm_f32(int32_t trans_a, int32_t trans_b, int32_t M, int32_t N, int32_t
  *   trans_a = 0:  C (M, N) = A B,    A (M, K), B (K, N)   -- input gradient dX = dY W     (K % 32 == 0)
  * N, lda, ldb, ldc multiples of 4 (M too for trans_a = 1), 16-byte aligned.  With few output tiles the reduction of the
  * trans_a = 1 form is split over workgroups into `workspace` (drm_gemm_split_workspace_bytes, may be 0; then ldc = N)
- * and summed in a fixed order. */
+ * and summed in a fixed order.  bf16_inputs = 1: the operands rounded to bf16 instead (one matrix instruction per product
+ * where the exact form has six; fp32 accumulation), the form the update side of a model run with bf16 matrix inputs takes. */
 size_t drm_gemm_split_workspace_bytes(int32_t trans_a, int32_t M, int32_t N, int32_t K);
-int drm_gemm_split_f32(int32_t trans_a, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda, const float* B,
-                       int64_t ldb, float* C, int64_t ldc, void* workspace, size_t workspace_bytes, drm_stream_t stream);
+int drm_gemm_split_f32(int32_t trans_a, int32_t bf16_inputs, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda,
+                       const float* B, int64_t ldb, float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
+                       drm_stream_t stream);
 
 /* Column sums of a row-major fp32 matrix, out[c] = sum_r x[r, c], rows added in a fixed order: the bias gradient autograd
  * forms for nn.Linear (lib/world_model.py:153-160 etc.: grad_bias = grad_output.sum(0)) and the sum over the slices of

@@ -69,3 +69,20 @@ def test_tower_with_native_convolutions_matches_the_backend(monkeypatch):
     _close(i1, i0.double(), 1e-5)
     for a, b in zip(g1, g0):
         _close(a, b.double(), 5e-5)
+
+
+@pytest.mark.parametrize("ni,hs,ws,cs,cb", [(20, 16, 16, 64, 32), (20, 8, 8, 128, 64), (20, 4, 4, 256, 128), (3, 5, 7, 64, 96)])
+def test_bf16_input_form_of_the_three_products(ni, hs, ws, cs, cb):
+    """precision 1: operands rounded to bf16, fp32 accumulation -- within 1e-2 of the fp64 result, and no longer the exact form."""
+    g = torch.Generator().manual_seed(ni + cs)
+    big = torch.randn(ni, cb, 2 * hs, 2 * ws, generator=g).to(DEV)
+    small = torch.randn(ni, cs, hs, ws, generator=g).to(DEV)
+    kern = (torch.randn(cs, cb, 4, 4, generator=g) * 0.1).to(DEV)
+    got = N.conv4s2_down(big, kern, bf16=True)
+    _close(got, F.conv2d(big.double(), kern.double(), stride=2, padding=1), 1e-2)
+    assert not torch.equal(got, N.conv4s2_down(big, kern))
+    _close(N.conv4s2_up(small, kern, bf16=True), F.conv_transpose2d(small.double(), kern.double(), stride=2, padding=1), 1e-2)
+    bigd = big.double().requires_grad_(True)
+    kd = kern.double().requires_grad_(True)
+    F.conv2d(bigd, kd, stride=2, padding=1).backward(small.double())
+    _close(N.conv4s2_wgrad(small, big, bf16=True), kd.grad, 1e-2)

@@ -81,3 +81,14 @@ def test_gradient_products_without_transposed_copies(M, Nn, K, ta):
     assert got.shape == (M, Nn)
     assert float((got.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max()) * max(1.0, (K / 1024) ** 0.5)
     assert torch.equal(got, N.gemm_split(a, b, ta))      # fixed-order reduction
+
+
+@pytest.mark.parametrize("M,Nn,K,ta", [(4096, 1536, 1024, True), (1024, 4096, 1024, False), (132, 260, 96, True)])
+def test_gradient_products_with_bf16_inputs(M, Nn, K, ta):
+    g = torch.Generator().manual_seed(M + Nn + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    b = torch.randn(K, Nn, generator=g).to(DEV)
+    got = N.gemm_split(a, b, ta, bf16=True)
+    ref = (a.double().t() if ta else a.double()) @ b.double()
+    assert float((got.double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
+    assert not torch.equal(got, N.gemm_split(a, b, ta))
