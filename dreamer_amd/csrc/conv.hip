@@ -837,7 +837,9 @@ extern "C" int drm_conv4s2_up_prec(const float* small, const float* kernel, floa
     const unsigned mtiles = (unsigned)((pixels + 127) / 128);
     // outputs of 32 columns: all four parity classes per workgroup (class by class a 128 x 32 tile has too few MFMAs per
     // staged value to pay for splitting it: 266 against 252 us of the fp32 form)
-    if (precision == 1 && cb > 32) {
+    if (precision == 1 && cb <= 32)                // rounding to bf16 costs a tenth of the exact split: class by class, 128 x 32 tiles
+        k_conv_split<CONV_UP, 1, 1, 1, 1><<<dim3(1, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
+    else if (precision == 1) {
         if (conv_wide_tiles(cb)) k_conv_split<CONV_UP, 2, 2, 2, 1><<<dim3(cb / 128, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
         else k_conv_split<CONV_UP, 2, 1, 2, 1><<<dim3((cb + 63) / 64, mtiles, 4), dim3(256), 0, (hipStream_t)stream>>>(g);
     } else if (conv_split_form() && cb <= 32 && std::getenv("DRM_CONV_NO_UP4") == nullptr)
