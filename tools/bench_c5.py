@@ -43,6 +43,21 @@ def update():
 
 
 ONLY = os.environ.get("C5_ONLY", "")          # "imagine16": just the few-row imagination block (for kernel traces)
+if ONLY == "ops_bf16":        # which framework ops (by input shape) launch what inside the bf16 update
+    from torch.profiler import profile, ProfilerActivity
+    wm.observe_precision = "bf16"
+    for _ in range(3):
+        update()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(2):
+            update()
+        torch.cuda.synchronize()
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    for e in rows[:70]:
+        print(f"{e.self_device_time_total / 2:8.1f} us/update {e.count / 2:6.1f} x {e.self_device_time_total / e.count:7.1f} us  {e.key[:44]:44s} {str(e.input_shapes)[:110]}")
+    sys.exit(0)
 for prec in (("f32",) if ONLY == "wm" else ("bf16",) if ONLY == "wm_bf16" else () if ONLY else ("f32", "bf16")):
     wm.observe_precision = prec
     out[f"wm_loss_backward_ms_16x64_{prec}"] = timeit(update, 5)
