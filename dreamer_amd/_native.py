@@ -87,7 +87,7 @@ class drm_observe_io(C.Structure):
 class drm_observe_bwd_io(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32)] + [(n, C.c_void_p) for n in (
         "c_prev", "y", "wmix", "psoft", "gates", "h_in", "g_h", "g_z", "g_post", "fc_w_hT", "gru_w_ihT", "gru_w_hhT",
-        "lin_zT", "d_gi", "d_gh", "d_x", "d_post", "workspace")] + [("workspace_bytes", C.c_size_t), ("precision", C.c_int32)]
+        "lin_zT", "d_gi", "d_gh", "d_x", "d_post", "workspace")] + [("workspace_bytes", C.c_size_t), ("precision", C.c_int32), ("gru_w_ih", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/dreamer_amd.h declares

@@ -767,8 +767,10 @@ extern "C" int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_
     const int B = io->B, T = io->T, D = d.D, L = d.L, LK = d.L * d.K;
     DRM_REQUIRE(B >= 1 && T >= 1, DRM_EINVAL, "B=%d T=%d", B, T);
     DRM_REQUIRE(io->c_prev && io->y && io->wmix && io->psoft && io->gates && io->h_in && io->g_h && io->g_z && io->g_post &&
-                    io->fc_w_hT && io->gru_w_ihT && io->gru_w_hhT && io->lin_zT && io->d_gi && io->d_gh && io->d_x && io->d_post,
+                    io->fc_w_hT && io->gru_w_hhT && io->lin_zT && io->d_gi && io->d_gh && io->d_x && io->d_post,
                 DRM_EINVAL, "null io pointer");
+    const bool x_from_w_ih = D > 512 && io->gru_w_ih != nullptr && (3 * D) % 32 == 0;
+    DRM_REQUIRE(io->gru_w_ihT || x_from_w_ih, DRM_EINVAL, "null io pointer (gru_w_ihT)");
     DRM_REQUIRE(io->workspace && io->workspace_bytes >= (size_t)B * 3 * D * sizeof(float) && aligned16(io->workspace),
                 DRM_EINVAL, "workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
@@ -820,6 +822,8 @@ extern "C" int drm_observe_backward_f32(const drm_dims* dims, const drm_observe_
                 DRM_LAUNCH_CHECK();
             }
         }
+        if (x_from_w_ih)       // d(x) = d(gi) W_ih over all (b, t) rows, W_ih read as it lies
+            return drm_gemm_split_f32(0, prec == 1, B * T, D, 3 * D, io->d_gi, 3 * D, io->gru_w_ih, D, io->d_x, D, nullptr, 0, stream);
         ProblemSpec px{io->d_gi, 3 * D, nullptr, nullptr, io->gru_w_ihT, 3 * D, nullptr, nullptr, 0, io->d_x, D, D, 3 * D};
         return launch_big(&px, 1, B * T, nullptr, 0, 0, 0, s, prec);
     }

@@ -43,6 +43,11 @@ def _scan_eager(wm, e_part, a_prev, c_prev, expo_reset, expo_z, state):
     return torch.stack(hs, 1), torch.stack(zs, 1), torch.stack(posts, 1), WorldModelState(h=h, z=z)
 
 
+def W_GRADIENT_STAGING() -> bool:
+    from . import world_model as W
+    return W._GRADIENT_STAGING
+
+
 def _wgrad_bf16_ok(dy, D):
     """Shapes the bf16 large-row kernel takes for dy.T @ x: a long sum over the rows, many output rows."""
     rows, n = dy.shape
@@ -148,7 +153,10 @@ class ObserveScanFn(torch.autograd.Function):
         ls = F.log_softmax(post, dim=-1)
         w_mix = torch.exp(ls + log1m - torch.logaddexp(ls + log1m, torch.full((), floor, dtype=ls.dtype, device=ls.device)))
         p_soft = ls.exp()
-        fcT, ihT, hhT = fc_w_h.t().contiguous(), w_ih.t().contiguous(), w_hh.t().contiguous()
+        # wide models form d(x) from weight_ih as it lies: no transposed copy of the (3D, D) weight
+        x_from_w_ih = D > 512 and (3 * D) % 32 == 0 and w_ih.is_contiguous() and W_GRADIENT_STAGING()
+        fcT, hhT = fc_w_h.t().contiguous(), w_hh.t().contiguous()
+        ihT = None if x_from_w_ih else w_ih.t().contiguous()
         d_gi = torch.empty(B, T, 3 * D, device=dev, dtype=h.dtype)
         d_gh = torch.empty_like(d_gi)
         d_x = torch.empty_like(x)
@@ -160,7 +168,8 @@ class ObserveScanFn(torch.autograd.Function):
         io.c_prev, io.y, io.wmix, io.psoft = c_prev.data_ptr(), y.data_ptr(), w_mix.data_ptr(), p_soft.data_ptr()
         io.gates, io.h_in = gates.data_ptr(), h_in.data_ptr()
         io.g_h, io.g_z, io.g_post = g_h.data_ptr(), g_z.data_ptr(), g_post.data_ptr()
-        io.fc_w_hT, io.gru_w_ihT, io.gru_w_hhT, io.lin_zT = fcT.data_ptr(), ihT.data_ptr(), hhT.data_ptr(), eng.pack.data_ptr()
+        io.fc_w_hT, io.gru_w_ihT, io.gru_w_hhT, io.lin_zT = fcT.data_ptr(), N.ptr(ihT), hhT.data_ptr(), eng.pack.data_ptr()
+        io.gru_w_ih = w_ih.data_ptr() if x_from_w_ih else None
         io.d_gi, io.d_gh, io.d_x, io.d_post = d_gi.data_ptr(), d_gh.data_ptr(), d_x.data_ptr(), d_post.data_ptr()
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         io.precision = eng.precision

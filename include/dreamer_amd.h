@@ -483,6 +483,9 @@ typedef struct drm_observe_bwd_io {
     float* d_post;            /* (B,T,L*K) */
     void* workspace; size_t workspace_bytes;   /* >= drm_observe_bwd_workspace_bytes */
     int32_t precision;        /* as in drm_observe_io (recurrent widths > 512 only) */
+    const float* gru_w_ih;    /* optional, recurrent widths > 512 with 3D % 32 == 0: weight_ih (3D, D) as it lies.  When set,
+                                 d_x = d_gi W_ih is formed from it (drm_gemm_split_f32) and gru_w_ihT may be NULL: no
+                                 transposed copy of the 3D x D weight per call */
 } drm_observe_bwd_io;
 
 size_t drm_observe_bwd_workspace_bytes(const drm_dims* dims, int32_t B);
