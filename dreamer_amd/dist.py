@@ -123,8 +123,7 @@ class FlatGrads:
         Convolution kernels keep their logical (O, I, kh, kw) shape; with channels-last towers their slot is laid
         out (O, kh, kw, I), the format the convolution backend then takes without transposing them on every call."""
         p, off = self.params[i], self.offsets[i]
-        # (the image-side kernels, 3 channels on one side, are read in their plain layout by the library's kernels)
-        if p.dim() == 4 and self.channels_last_kernels and min(p.shape[0], p.shape[1]) > 4:
+        if p.dim() == 4 and self.channels_last_kernels:
             return buf[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
         return buf[off:off + p.numel()].view_as(p)
 
