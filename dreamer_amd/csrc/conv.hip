@@ -295,15 +295,33 @@ __global__ __launch_bounds__(256) void k_conv_gemm(const ConvArgs G) {
     }
 }
 
+// out = sum over the slices of partial, in a fixed order.  A workgroup owns 32 consecutive 16-byte outputs; its 8 groups of
+// 32 threads add every eighth slice each (four loads in flight per thread), and group 0 adds the eight sums in group order.
+// Many threads per output on purpose: the partials are 17-34 MB for a 2 MB result, and one thread walking 128 slices of an
+// output is a chain of load latencies (19 us); 8 x more loads in flight stream them.
 __global__ __launch_bounds__(256) void k_conv_reduce(const float* __restrict__ partial, int splits, int64_t total4,
                                                       float* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        f32x4 s = reinterpret_cast<const f32x4*>(partial)[i];
-        for (int z = 1; z < splits; ++z) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(partial)[(int64_t)z * total4 + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    __shared__ f32x4 red[8][32];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + o;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < total4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(partial) + i;
+        int z = g;
+        for (; z + 24 < splits; z += 32) {
+            const f32x4 v0 = p[(int64_t)z * total4], v1 = p[(int64_t)(z + 8) * total4], v2 = p[(int64_t)(z + 16) * total4],
+                        v3 = p[(int64_t)(z + 24) * total4];
+            acc += v0; acc += v1; acc += v2; acc += v3;
         }
-        reinterpret_cast<f32x4*>(out)[i] = s;
+        for (; z < splits; z += 8) acc += p[(int64_t)z * total4];
+    }
+    red[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && i < total4) {
+        f32x4 t = red[0][o];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += red[q][o];
+        reinterpret_cast<f32x4*>(out)[i] = t;
     }
 }
 
@@ -900,9 +918,8 @@ extern "C" int drm_conv4s2_wgrad_prec(const float* small, const float* big, floa
     }
     if (splits > 1) {
         const int64_t total4 = (int64_t)cs * 16 * cb / 4;
-        const int64_t blocks = (total4 + 255) / 256;
         ProfScope prof(PC_ELEMENTWISE, s, (double)splits * total4 * 4, 16.0 * (splits + 1.0) * total4);
-        k_conv_reduce<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s>>>(g.partial, splits, total4, kernel_grad_out);
+        k_conv_reduce<<<dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, s>>>(g.partial, splits, total4, kernel_grad_out);
         DRM_LAUNCH_CHECK();
     }
     return DRM_OK;
@@ -950,8 +967,7 @@ extern "C" int drm_gemm_split_f32(int32_t trans_a, int32_t bf16_inputs, int32_t 
         DRM_LAUNCH_CHECK();
         if (splits > 1) {
             const int64_t total4 = (int64_t)M * N / 4;
-            const int64_t blocks = (total4 + 255) / 256;
-            k_conv_reduce<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s>>>(g.partial, splits, total4, C);
+            k_conv_reduce<<<dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, s>>>(g.partial, splits, total4, C);
             DRM_LAUNCH_CHECK();
         }
     } else {                                        // C = A B, A (M, K)
